@@ -1,0 +1,184 @@
+"""dmc4 / dmc6 weight files: tensor catalogue, synthetic generator, writer, reader.
+
+The file format is the reference's ggml-style container and is a KEPT SURFACE:
+  writer  : /root/reference/scripts/convert-pth-to-ggml.py:111-140
+  reader  : /root/reference/src/model_load.cpp:79-147 (+ fp16 widening :1092-1300)
+little-endian  u32 magic ("dmc4" 0x646d6334 | "dmc6" 0x646d6336) then records
+  {i32 n_dims; i32 name_len; i32 ne[n_dims]; char name[name_len]; f16 data[prod(ne)]}
+in C order, shapes after ``squeeze()`` (size-1 axes removed).
+
+There are no real checkpoints in this environment (no network), so benchmarks and
+parity tests use synthetic weights in exactly this format.
+The product loader (csrc/model_load.cpp) and the oracle's loader both read these files.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+MAGIC_4S = 0x646D6334
+MAGIC_6S = 0x646D6336
+
+
+def _squeeze(shape):
+    return tuple(int(s) for s in shape if s != 1)
+
+
+def tensor_catalogue(n_sources: int = 4) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(name, squeezed shape) for every tensor of htdemucs (4s: 533, 6s: 525).
+
+    Shapes: /root/reference/src/model.hpp:26-554, names:
+    /root/reference/src/model_load.cpp:156-1062."""
+    assert n_sources in (4, 6)
+    D = 512 if n_sources == 4 else 384
+    FF = 4 * D
+    S = n_sources
+    ch = [48, 96, 192, 384]
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def add(name, shape):
+        out.append((name, _squeeze(shape)))
+
+    def dconv(prefix, C):
+        for j in range(2):
+            p = f"{prefix}.dconv.layers.{j}"
+            add(f"{p}.0.weight", (C // 8, C, 3))
+            add(f"{p}.0.bias", (C // 8,))
+            add(f"{p}.1.weight", (C // 8,))
+            add(f"{p}.1.bias", (C // 8,))
+            add(f"{p}.3.weight", (2 * C, C // 8, 1))
+            add(f"{p}.3.bias", (2 * C,))
+            add(f"{p}.4.weight", (2 * C,))
+            add(f"{p}.4.bias", (2 * C,))
+            add(f"{p}.6.scale", (C,))
+
+    for i in range(4):
+        C = ch[i]
+        cin_f = 4 if i == 0 else ch[i - 1]
+        cin_t = 2 if i == 0 else ch[i - 1]
+        add(f"encoder.{i}.conv.weight", (C, cin_f, 8, 1))
+        add(f"encoder.{i}.conv.bias", (C,))
+        add(f"encoder.{i}.rewrite.weight", (2 * C, C, 1, 1))
+        add(f"encoder.{i}.rewrite.bias", (2 * C,))
+        dconv(f"encoder.{i}", C)
+        add(f"tencoder.{i}.conv.weight", (C, cin_t, 8))
+        add(f"tencoder.{i}.conv.bias", (C,))
+        add(f"tencoder.{i}.rewrite.weight", (2 * C, C, 1))
+        add(f"tencoder.{i}.rewrite.bias", (2 * C,))
+        dconv(f"tencoder.{i}", C)
+    for k in range(4):
+        Cd = ch[3 - k]
+        cout_f = ch[2 - k] if k < 3 else 4 * S
+        cout_t = ch[2 - k] if k < 3 else 2 * S
+        add(f"decoder.{k}.conv_tr.weight", (Cd, cout_f, 8, 1))
+        add(f"decoder.{k}.conv_tr.bias", (cout_f,))
+        add(f"decoder.{k}.rewrite.weight", (2 * Cd, Cd, 3, 3))
+        add(f"decoder.{k}.rewrite.bias", (2 * Cd,))
+        dconv(f"decoder.{k}", Cd)
+        add(f"tdecoder.{k}.conv_tr.weight", (Cd, cout_t, 8))
+        add(f"tdecoder.{k}.conv_tr.bias", (cout_t,))
+        add(f"tdecoder.{k}.rewrite.weight", (2 * Cd, Cd, 3))
+        add(f"tdecoder.{k}.rewrite.bias", (2 * Cd,))
+        dconv(f"tdecoder.{k}", Cd)
+    add("freq_emb.embedding.weight", (512, 48))
+    if n_sources == 4:
+        for nm, (o, i_) in (("channel_upsampler", (512, 384)), ("channel_downsampler", (384, 512)),
+                            ("channel_upsampler_t", (512, 384)), ("channel_downsampler_t", (384, 512))):
+            add(f"{nm}.weight", (o, i_, 1))
+            add(f"{nm}.bias", (o,))
+    for nm in ("norm_in", "norm_in_t"):
+        add(f"crosstransformer.{nm}.weight", (D,))
+        add(f"crosstransformer.{nm}.bias", (D,))
+    for layer in range(5):
+        for sfx in ("", "_t"):
+            p = f"crosstransformer.layers{sfx}.{layer}"
+            attn = "self_attn" if layer % 2 == 0 else "cross_attn"
+            add(f"{p}.{attn}.in_proj_weight", (3 * D, D))
+            add(f"{p}.{attn}.in_proj_bias", (3 * D,))
+            add(f"{p}.{attn}.out_proj.weight", (D, D))
+            add(f"{p}.{attn}.out_proj.bias", (D,))
+            add(f"{p}.linear1.weight", (FF, D))
+            add(f"{p}.linear1.bias", (FF,))
+            add(f"{p}.linear2.weight", (D, FF))
+            add(f"{p}.linear2.bias", (D,))
+            norms = ("norm1", "norm2", "norm_out") if layer % 2 == 0 else ("norm1", "norm2", "norm3", "norm_out")
+            for n in norms:
+                add(f"{p}.{n}.weight", (D,))
+                add(f"{p}.{n}.bias", (D,))
+            add(f"{p}.gamma_1.scale", (D,))
+            add(f"{p}.gamma_2.scale", (D,))
+    return out
+
+
+def synth_weights(n_sources: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic fp16 weights: N(0, 1/fan_in) for linear /
+    conv kernels, norm weights 1 +- 0.1, biases 0.01 N(0,1), LayerScale tensors
+    U(0.05, 0.5) so that every residual branch moves the output measurably."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in tensor_catalogue(n_sources):
+        n = int(np.prod(shape))
+        if name.endswith(".scale"):
+            a = rng.uniform(0.05, 0.5, size=shape)
+        elif name == "freq_emb.embedding.weight":
+            a = 0.5 * rng.standard_normal(shape)
+        elif name.endswith("bias") or name.endswith("in_proj_bias"):
+            if ".norm" in name or ".1.bias" in name or ".4.bias" in name:
+                a = 0.05 * rng.standard_normal(shape)
+            else:
+                a = 0.01 * rng.standard_normal(shape)
+        elif ".norm" in name or name.endswith(".1.weight") or name.endswith(".4.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        else:
+            if "conv_tr" in name:
+                fan_in = 2 * shape[0]  # every output sample sees 2 taps x Cin
+            else:
+                fan_in = n // shape[0]
+            a = rng.standard_normal(shape) / np.sqrt(float(fan_in))
+        out[name] = np.ascontiguousarray(a.astype(np.float16))
+    return out
+
+
+def write_model(path: str, tensors: Dict[str, np.ndarray], n_sources: int) -> None:
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", MAGIC_4S if n_sources == 4 else MAGIC_6S))
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr.astype(np.float16))
+            nm = name.encode("utf-8")
+            f.write(struct.pack("<ii", a.ndim, len(nm)))
+            for d in a.shape:
+                f.write(struct.pack("<i", int(d)))
+            f.write(nm)
+            f.write(a.tobytes())
+
+
+def read_model(path: str) -> Tuple[int, Dict[str, np.ndarray]]:
+    """Independent numpy reader (used by the fp64 golden model and by tests)."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    (magic,) = struct.unpack_from("<I", buf, 0)
+    if magic == MAGIC_4S:
+        ns = 4
+    elif magic == MAGIC_6S:
+        ns = 6
+    else:
+        raise ValueError("bad magic")
+    pos = 4
+    out: Dict[str, np.ndarray] = {}
+    while pos < len(buf):
+        nd, ln = struct.unpack_from("<ii", buf, pos)
+        pos += 8
+        shape = struct.unpack_from("<" + "i" * nd, buf, pos)
+        pos += 4 * nd
+        name = buf[pos:pos + ln].decode("utf-8")
+        pos += ln
+        n = int(np.prod(shape)) if nd else 1
+        out[name] = np.frombuffer(buf, dtype="<f2", count=n, offset=pos).reshape(shape).copy()
+        pos += 2 * n
+    return ns, out
+
+
+def write_synthetic_model(path: str, n_sources: int = 4, seed: int = 0) -> None:
+    write_model(path, synth_weights(n_sources, seed), n_sources)
