@@ -1,0 +1,474 @@
+// model_pack.cpp — dmc4/dmc6 weight-file reader and repacking into GEMM-ready layouts.
+//
+// File format (kept surface): /root/reference/src/model_load.cpp:79-147 (reader) and
+// /root/reference/scripts/convert-pth-to-ggml.py:111-140 (writer). Error behaviour
+// mirrors the reference loader: open failure, bad magic, unknown tensor name or
+// element-count mismatch => false + message (model_load.cpp:64-69,97-102,1065-1070,
+// 1096-1105). Unlike the reference we ALSO fail when a tensor is missing.
+//
+// Packing (done once on the host, then the blob lives in HBM):
+//   * every conv / linear weight becomes a row-major matrix Wt[Np][Kp] (Np = N rounded
+//     up to 16, Kp = K rounded up to 16, zero padded) with K ordered exactly like the
+//     contiguous activation runs of the channels-last layout (tap-major, channel
+//     fastest), so the conv is one GEMM with no im2col (plan.h);
+//   * GLU producers get their 2C rows interleaved in blocks of 16 (a16|b16) so the two
+//     gate halves of a channel sit in adjacent MFMA fragments of one wave;
+//   * transposed convs k8/s4 become N = 4*Cout, K = 2*Cin: out[4q+r] = [x[q-1], x[q]] .
+//     [W[:,co,r+4]; W[:,co,r]] (no zero stuffing, cf. src/conv.hpp:264-325).
+#include "plan.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace dmx
+{
+
+static float half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, f;
+    if (e == 0)
+    {
+        if (m == 0)
+            f = sign;
+        else
+        {
+            int sh = 0;
+            while ((m & 0x400u) == 0)
+            {
+                m <<= 1;
+                ++sh;
+            }
+            m &= 0x3ffu;
+            f = sign | ((uint32_t)(113 - sh) << 23) | (m << 13);
+        }
+    }
+    else if (e == 31)
+        f = sign | 0x7f800000u | (m << 13);
+    else
+        f = sign | ((e + 112) << 23) | (m << 13);
+    float out;
+    std::memcpy(&out, &f, 4);
+    return out;
+}
+
+struct Raw
+{
+    std::vector<int> shape;
+    std::vector<float> d;
+    i64 numel() const { return (i64)d.size(); }
+};
+
+
+i64 PackedModel::find(const std::string &name) const
+{
+    for (auto &kv : index)
+        if (kv.first == name)
+            return kv.second;
+    fprintf(stderr, "[dmx] internal error: packed array '%s' not found\n", name.c_str());
+    abort();
+}
+
+namespace
+{
+struct Packer
+{
+    PackedModel &pm;
+    const std::map<std::string, Raw> &raw;
+    explicit Packer(PackedModel &p, const std::map<std::string, Raw> &r) : pm(p), raw(r) {}
+
+    const Raw &get(const std::string &n) const { return raw.at(n); }
+
+    float *alloc(const std::string &name, i64 n)
+    {
+        i64 off = (i64)pm.blob.size();
+        off = (off + 63) / 64 * 64; // 256-byte aligned arrays
+        pm.blob.resize((size_t)(off + n), 0.0f);
+        pm.index.emplace_back(name, off);
+        return pm.blob.data() + off;
+    }
+    // packed row index of logical GLU row (c, half) -- blocks of 16: a16 | b16
+    static int paired_row(int c, int half) { return (c / 16) * 32 + half * 16 + (c % 16); }
+
+    // plain vector copy, padded
+    void vec(const std::string &dst, const std::string &src, int npad)
+    {
+        const Raw &r = get(src);
+        float *p = alloc(dst, npad);
+        for (i64 i = 0; i < r.numel(); ++i)
+            p[i] = r.d[(size_t)i];
+    }
+    // vector of length 2C in paired order
+    void vec_paired(const std::string &dst, const std::string &src)
+    {
+        const Raw &r = get(src);
+        int C = (int)r.numel() / 2;
+        float *p = alloc(dst, 2 * C);
+        for (int c = 0; c < C; ++c)
+        {
+            p[paired_row(c, 0)] = r.d[(size_t)c];
+            p[paired_row(c, 1)] = r.d[(size_t)(C + c)];
+        }
+    }
+    // generic conv / linear weight (N, Cin, taps...) -> Wt[Np][Kp], k = tapidx*Cin + ci.
+    // `tapmap[t]` gives the source flat tap index (over the trailing dims) of packed tap t.
+    void conv(const std::string &dst, const std::string &src, int N, int Cin, const std::vector<int> &tapmap,
+              bool paired, int Npad_extra = 0)
+    {
+        const Raw &r = get(src);
+        int taps = (int)tapmap.size();
+        int K = taps * Cin, Kp = rup(K, 16), Np = rup(std::max(N, Npad_extra), 16);
+        float *p = alloc(dst, (i64)Np * Kp);
+        int srcTaps = (int)(r.numel() / ((i64)N * Cin));
+        for (int n = 0; n < N; ++n)
+        {
+            int row = n;
+            if (paired)
+            {
+                int C = N / 2;
+                row = (n < C) ? paired_row(n, 0) : paired_row(n - C, 1);
+            }
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    p[(i64)row * Kp + t * Cin + ci] = r.d[(size_t)(((i64)n * Cin + ci) * srcTaps + tapmap[(size_t)t])];
+        }
+    }
+    // transposed conv (Cin, Cout, 8) -> Wt[4*Cout][2*Cin], bias[4*Cout]
+    void conv_tr(const std::string &dstW, const std::string &dstB, const std::string &srcW, const std::string &srcB)
+    {
+        const Raw &r = get(srcW);
+        const Raw &b = get(srcB);
+        int Cout = (int)b.numel();
+        int Cin = (int)(r.numel() / ((i64)Cout * 8));
+        int N = 4 * Cout, K = 2 * Cin, Kp = rup(K, 16), Np = rup(N, 16);
+        float *p = alloc(dstW, (i64)Np * Kp);
+        for (int rr = 0; rr < 4; ++rr)
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                {
+                    i64 row = (i64)(rr * Cout + co) * Kp;
+                    p[row + 0 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * 8 + rr + 4)]; // x[q-1] * W[.., r+4]
+                    p[row + 1 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * 8 + rr)];     // x[q]   * W[.., r]
+                }
+        float *pb = alloc(dstB, Np);
+        for (int rr = 0; rr < 4; ++rr)
+            for (int co = 0; co < Cout; ++co)
+                pb[rr * Cout + co] = b.d[(size_t)co];
+    }
+
+    void dconv(const std::string &p, int C)
+    {
+        int C8 = C / 8, C8p = rup(C8, 4);
+        for (int j = 0; j < 2; ++j)
+        {
+            std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
+            std::string d = p + ".dconv." + std::to_string(j) + ".";
+            // k1: Conv1d(C -> C/8, k3, dilation): N = C8p (zero rows for the pad columns)
+            conv(d + "k1.Wt", s + "0.weight", C8, C, {0, 1, 2}, false, C8p);
+            vec(d + "k1.b", s + "0.bias", rup(C8p, 16));
+            // GroupNorm(1, C/8) affine, indexed by k of the next GEMM
+            vec(d + "gn1.w", s + "1.weight", rup(C8p, 16));
+            vec(d + "gn1.b", s + "1.bias", rup(C8p, 16));
+            // k2: Conv1d(C/8 -> 2C, 1x1), paired rows, K = C8p
+            {
+                const Raw &r = get(s + "3.weight");
+                int N = 2 * C, Kp = rup(C8p, 16);
+                float *w = alloc(d + "k2.Wt", (i64)N * Kp);
+                for (int n = 0; n < N; ++n)
+                {
+                    int row = (n < C) ? paired_row(n, 0) : paired_row(n - C, 1);
+                    for (int k = 0; k < C8; ++k)
+                        w[(i64)row * Kp + k] = r.d[(size_t)((i64)n * C8 + k)];
+                }
+            }
+            vec_paired(d + "k2.b", s + "3.bias");
+            vec_paired(d + "gn2.w", s + "4.weight");
+            vec_paired(d + "gn2.b", s + "4.bias");
+            vec(d + "scale", s + "6.scale", C);
+        }
+    }
+};
+} // namespace
+
+static bool expected_shapes(int ns, std::map<std::string, i64> &exp)
+{
+    // element counts per tensor name; /root/reference/src/model.hpp:26-554
+    const int D = ns == 4 ? 512 : 384, FF = 4 * D, S = ns;
+    const int ch[4] = {48, 96, 192, 384};
+    auto dconv = [&](const std::string &p, int C) {
+        for (int j = 0; j < 2; ++j)
+        {
+            std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
+            exp[s + "0.weight"] = (i64)(C / 8) * C * 3;
+            exp[s + "0.bias"] = C / 8;
+            exp[s + "1.weight"] = C / 8;
+            exp[s + "1.bias"] = C / 8;
+            exp[s + "3.weight"] = (i64)2 * C * (C / 8);
+            exp[s + "3.bias"] = 2 * C;
+            exp[s + "4.weight"] = 2 * C;
+            exp[s + "4.bias"] = 2 * C;
+            exp[s + "6.scale"] = C;
+        }
+    };
+    for (int i = 0; i < 4; ++i)
+    {
+        int C = ch[i], cf = i == 0 ? 4 : ch[i - 1], ct = i == 0 ? 2 : ch[i - 1];
+        std::string e = "encoder." + std::to_string(i), t = "tencoder." + std::to_string(i);
+        exp[e + ".conv.weight"] = (i64)C * cf * 8;
+        exp[e + ".conv.bias"] = C;
+        exp[e + ".rewrite.weight"] = (i64)2 * C * C;
+        exp[e + ".rewrite.bias"] = 2 * C;
+        dconv(e, C);
+        exp[t + ".conv.weight"] = (i64)C * ct * 8;
+        exp[t + ".conv.bias"] = C;
+        exp[t + ".rewrite.weight"] = (i64)2 * C * C;
+        exp[t + ".rewrite.bias"] = 2 * C;
+        dconv(t, C);
+    }
+    for (int k = 0; k < 4; ++k)
+    {
+        int Cd = ch[3 - k], cf = k < 3 ? ch[2 - k] : 4 * S, ct = k < 3 ? ch[2 - k] : 2 * S;
+        std::string d = "decoder." + std::to_string(k), t = "tdecoder." + std::to_string(k);
+        exp[d + ".conv_tr.weight"] = (i64)Cd * cf * 8;
+        exp[d + ".conv_tr.bias"] = cf;
+        exp[d + ".rewrite.weight"] = (i64)2 * Cd * Cd * 9;
+        exp[d + ".rewrite.bias"] = 2 * Cd;
+        dconv(d, Cd);
+        exp[t + ".conv_tr.weight"] = (i64)Cd * ct * 8;
+        exp[t + ".conv_tr.bias"] = ct;
+        exp[t + ".rewrite.weight"] = (i64)2 * Cd * Cd * 3;
+        exp[t + ".rewrite.bias"] = 2 * Cd;
+        dconv(t, Cd);
+    }
+    exp["freq_emb.embedding.weight"] = 512 * 48;
+    if (ns == 4)
+    {
+        const char *nm[4] = {"channel_upsampler", "channel_downsampler", "channel_upsampler_t", "channel_downsampler_t"};
+        for (int i = 0; i < 4; ++i)
+        {
+            exp[std::string(nm[i]) + ".weight"] = 512 * 384;
+            exp[std::string(nm[i]) + ".bias"] = (i % 2 == 0) ? 512 : 384;
+        }
+    }
+    for (const char *nm : {"norm_in", "norm_in_t"})
+    {
+        exp[std::string("crosstransformer.") + nm + ".weight"] = D;
+        exp[std::string("crosstransformer.") + nm + ".bias"] = D;
+    }
+    for (int layer = 0; layer < 5; ++layer)
+        for (const char *sfx : {"", "_t"})
+        {
+            std::string p = std::string("crosstransformer.layers") + sfx + "." + std::to_string(layer);
+            std::string a = p + (layer % 2 == 0 ? ".self_attn" : ".cross_attn");
+            exp[a + ".in_proj_weight"] = (i64)3 * D * D;
+            exp[a + ".in_proj_bias"] = 3 * D;
+            exp[a + ".out_proj.weight"] = (i64)D * D;
+            exp[a + ".out_proj.bias"] = D;
+            exp[p + ".linear1.weight"] = (i64)FF * D;
+            exp[p + ".linear1.bias"] = FF;
+            exp[p + ".linear2.weight"] = (i64)D * FF;
+            exp[p + ".linear2.bias"] = D;
+            for (const char *n : {"norm1", "norm2", "norm_out"})
+            {
+                exp[p + "." + n + ".weight"] = D;
+                exp[p + "." + n + ".bias"] = D;
+            }
+            if (layer % 2 == 1)
+            {
+                exp[p + ".norm3.weight"] = D;
+                exp[p + ".norm3.bias"] = D;
+            }
+            exp[p + ".gamma_1.scale"] = D;
+            exp[p + ".gamma_2.scale"] = D;
+        }
+    return true;
+}
+
+bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+    {
+        err = "load_demucs_model: failed to open " + path;
+        return false;
+    }
+    uint32_t magic = 0;
+    if (fread(&magic, 4, 1, f) != 1)
+    {
+        fclose(f);
+        err = "load_demucs_model: invalid model data (short file)";
+        return false;
+    }
+    if (magic == 0x646d6336u)
+    {
+        pm.n_sources = 6;
+        pm.dim = 384;
+    }
+    else if (magic == 0x646d6334u)
+    {
+        pm.n_sources = 4;
+        pm.dim = 512;
+    }
+    else
+    {
+        fclose(f);
+        err = "load_demucs_model: invalid model data (bad magic)";
+        return false;
+    }
+    std::map<std::string, i64> exp;
+    expected_shapes(pm.n_sources, exp);
+    std::map<std::string, Raw> raw;
+    for (;;)
+    {
+        int32_t n_dims = 0, length = 0;
+        if (fread(&n_dims, 4, 1, f) != 1)
+            break;
+        if (fread(&length, 4, 1, f) != 1)
+            break;
+        if (n_dims < 0 || n_dims > 4 || length <= 0 || length > 1024)
+        {
+            fclose(f);
+            err = "load_demucs_model: corrupt tensor header";
+            return false;
+        }
+        Raw r;
+        i64 nel = 1;
+        for (int i = 0; i < n_dims; ++i)
+        {
+            int32_t ne = 0;
+            if (fread(&ne, 4, 1, f) != 1)
+            {
+                fclose(f);
+                err = "load_demucs_model: truncated file";
+                return false;
+            }
+            r.shape.push_back(ne);
+            nel *= ne;
+        }
+        std::string name((size_t)length, '\0');
+        if (fread(&name[0], 1, (size_t)length, f) != (size_t)length)
+        {
+            fclose(f);
+            err = "load_demucs_model: truncated file";
+            return false;
+        }
+        auto it = exp.find(name);
+        if (it == exp.end())
+        {
+            fclose(f);
+            err = "load_demucs_model: failed to load " + name + " (unknown tensor)";
+            return false;
+        }
+        if (it->second != nel)
+        {
+            fclose(f);
+            err = "load_demucs_model: tensor '" + name + "' has wrong size in model file";
+            return false;
+        }
+        std::vector<uint16_t> h((size_t)nel);
+        if (fread(h.data(), 2, (size_t)nel, f) != (size_t)nel)
+        {
+            fclose(f);
+            err = "load_demucs_model: truncated tensor data for " + name;
+            return false;
+        }
+        r.d.resize((size_t)nel);
+        for (i64 i = 0; i < nel; ++i)
+            r.d[(size_t)i] = half_to_float(h[(size_t)i]);
+        raw[name] = std::move(r);
+        pm.n_tensors++;
+    }
+    fclose(f);
+    for (auto &kv : exp)
+        if (!raw.count(kv.first))
+        {
+            err = "load_demucs_model: tensor '" + kv.first + "' missing from model file";
+            return false;
+        }
+
+    // ---------------- pack ----------------
+    Packer P(pm, raw);
+    const int ch[4] = {48, 96, 192, 384};
+    const int S = pm.n_sources, D = pm.dim;
+    std::vector<int> taps8 = {0, 1, 2, 3, 4, 5, 6, 7}, taps3 = {0, 1, 2}, tap1 = {0};
+    for (int i = 0; i < 4; ++i)
+    {
+        int C = ch[i], cf = i == 0 ? 4 : ch[i - 1], ct = i == 0 ? 2 : ch[i - 1];
+        for (int br = 0; br < 2; ++br)
+        {
+            std::string p = std::string(br == 0 ? "encoder." : "tencoder.") + std::to_string(i);
+            P.conv(p + ".conv.Wt", p + ".conv.weight", C, br == 0 ? cf : ct, taps8, false);
+            P.vec(p + ".conv.b", p + ".conv.bias", rup(C, 16));
+            P.dconv(p, C);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * C, C, tap1, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+        }
+    }
+    for (int k = 0; k < 4; ++k)
+    {
+        int Cd = ch[3 - k];
+        {
+            std::string p = "decoder." + std::to_string(k);
+            // 3x3 over (F=kh, T=kw); our K order is (s1 = kw over T, then kh over F, then ci)
+            std::vector<int> tm;
+            for (int kw = 0; kw < 3; ++kw)
+                for (int kh = 0; kh < 3; ++kh)
+                    tm.push_back(kh * 3 + kw);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * Cd, Cd, tm, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+            P.dconv(p, Cd);
+            P.conv_tr(p + ".conv_tr.Wt", p + ".conv_tr.b", p + ".conv_tr.weight", p + ".conv_tr.bias");
+        }
+        {
+            std::string p = "tdecoder." + std::to_string(k);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * Cd, Cd, taps3, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+            P.dconv(p, Cd);
+            P.conv_tr(p + ".conv_tr.Wt", p + ".conv_tr.b", p + ".conv_tr.weight", p + ".conv_tr.bias");
+        }
+    }
+    (void)S;
+    P.vec("freq_emb.table", "freq_emb.embedding.weight", 512 * 48);
+    if (pm.n_sources == 4)
+        for (const char *nm : {"channel_upsampler", "channel_downsampler", "channel_upsampler_t", "channel_downsampler_t"})
+        {
+            const Raw &b = raw.at(std::string(nm) + ".bias");
+            int N = (int)b.numel();
+            int Cin = (int)(raw.at(std::string(nm) + ".weight").numel() / N);
+            P.conv(std::string(nm) + ".Wt", std::string(nm) + ".weight", N, Cin, tap1, false);
+            P.vec(std::string(nm) + ".b", std::string(nm) + ".bias", rup(N, 16));
+        }
+    for (const char *nm : {"norm_in", "norm_in_t"})
+    {
+        P.vec(std::string("crosstransformer.") + nm + ".w", std::string("crosstransformer.") + nm + ".weight", D);
+        P.vec(std::string("crosstransformer.") + nm + ".b", std::string("crosstransformer.") + nm + ".bias", D);
+    }
+    for (int layer = 0; layer < 5; ++layer)
+        for (const char *sfx : {"", "_t"})
+        {
+            std::string p = std::string("crosstransformer.layers") + sfx + "." + std::to_string(layer);
+            std::string a = p + (layer % 2 == 0 ? ".self_attn" : ".cross_attn");
+            P.conv(p + ".in_proj.Wt", a + ".in_proj_weight", 3 * D, D, tap1, false);
+            P.vec(p + ".in_proj.b", a + ".in_proj_bias", 3 * D);
+            P.conv(p + ".out_proj.Wt", a + ".out_proj.weight", D, D, tap1, false);
+            P.vec(p + ".out_proj.b", a + ".out_proj.bias", D);
+            P.conv(p + ".linear1.Wt", p + ".linear1.weight", 4 * D, D, tap1, false);
+            P.vec(p + ".linear1.b", p + ".linear1.bias", 4 * D);
+            P.conv(p + ".linear2.Wt", p + ".linear2.weight", D, 4 * D, tap1, false);
+            P.vec(p + ".linear2.b", p + ".linear2.bias", D);
+            for (const char *n : {"norm1", "norm2", "norm3", "norm_out"})
+            {
+                if (std::string(n) == "norm3" && layer % 2 == 0)
+                    continue;
+                P.vec(p + "." + n + ".w", p + "." + n + ".weight", D);
+                P.vec(p + "." + n + ".b", p + "." + n + ".bias", D);
+            }
+            P.vec(p + ".gamma_1", p + ".gamma_1.scale", D);
+            P.vec(p + ".gamma_2", p + ".gamma_2.scale", D);
+        }
+    return true;
+}
+
+} // namespace dmx

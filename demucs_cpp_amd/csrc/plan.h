@@ -1,0 +1,248 @@
+// plan.h — the per-segment execution plan: a flat list of ops over two address spaces.
+//
+//   W space : packed model weights (one float blob per model, resident in HBM)
+//   A space : per-context arena (constants such as window / twiddles / positional
+//             tables first, then activations), one float blob per context in HBM
+//
+// Every `i64` field named *_w is an element offset into W, every other offset is into
+// A. The plan is pure data: it is built once per context by plan.cpp (shapes are
+// static for a given segment length and batch), executed by the HIP kernels in
+// engine.cpp, and - in tests only - interpreted on the CPU by tests/cpu_interp.cpp to
+// validate packing and index math without a GPU.
+//
+// Activation layouts (all fp32, channels-last; chosen so that every conv in the model
+// is a GEMM whose A rows are contiguous runs of memory):
+//   freq branch   [B][T][F][C]   (T = STFT frames of the segment, F = freq bins)
+//   time branch   [B][L][C]
+//   tokens        [B][tok][D]    (freq tokens tok = t*8 + f: exactly [T][F=8][C])
+// which is also the physical order of the reference's column-major Eigen tensors
+// (C fastest; /root/reference/src/tensor.hpp:24-28).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace dmx
+{
+typedef int64_t i64;
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+enum OpKind
+{
+    OP_IGEMM = 0,
+    OP_STATS_REDUCE,
+    OP_STFT,
+    OP_LAYERNORM,
+    OP_GN_APPLY,
+    OP_ATTENTION,
+    OP_ISTFT,
+    OP_OLA,
+    OP_TAP, // no-op marker: names an activation for the debug-tap API
+};
+
+enum Prologue
+{
+    PRO_NONE = 0,
+    PRO_AFFINE = 1,  // a = (a - st[b].mean) * st[b].scale          (z-norm fused into enc0)
+    PRO_GN_GELU = 2, // a = gelu((a - st[g].mean)*st[g].scale*pw[k] + pb[k])
+};
+
+enum Epilogue
+{
+    EPI_LINEAR = 0,            // v = acc+bias; act; += res; store [row][n]
+    EPI_SCALE_RES = 1,         // v = res + (acc+bias)*scale[n]; store
+    EPI_GLU = 2,               // paired cols: v = a*sigmoid(b) (+ tableScale*table[p0][c]); store [row][c]
+    EPI_GN_GLU_SCALE_RES = 3,  // paired cols after GroupNorm: v = res + scale[c]*glu(gn(a),gn(b))
+    EPI_STATS_ONLY = 4,        // row statistics of (acc+bias) only, nothing stored
+    EPI_TRCONV = 5,            // n=(r,co): j = 4*p0 + r - 2; store [(b,p1,j)][co]; act; += res
+};
+
+// Statistics records are 4 floats: {mean, scale, std, 0}; scale is rstd = 1/sqrt(var+eps)
+// (MODE_RSTD; GroupNorm/LayerNorm, Q3 unbiased var) or 1/(std+eps) (MODE_ZNORM).
+enum StatsMode
+{
+    MODE_RSTD = 0,
+    MODE_ZNORM = 1,
+};
+
+struct IGemm
+{
+    // ---- rows: m -> (b, p1, p0), M = B*P1*P0
+    int B, P1, P0;
+    // ---- A operand: input tensor [B][L1][L0][Cin] at `x` with explicit batch stride
+    i64 x, xBatchStride;
+    int L1, L0, Cin;
+    int S1, stride1, dil1, pad1; // taps along axis 1: in1 = p1*stride1 + s1*dil1 - pad1
+    int seg0, stride0, pad0;     // inner contiguous run: elements [(p0*stride0-pad0)*Cin, +seg0)
+                                 // of the inner row, zero outside [0, L0*Cin)
+    int K;                       // S1*seg0 (logical K); weight rows are Kp = roundup(K,16) long
+    int Kp;
+    // ---- prologue
+    int pro;
+    i64 proStats; // A: PRO_AFFINE [B][4]; PRO_GN_GELU [B*G0][4]
+    i64 proW_w, proB_w; // W: [Kp] (PRO_GN_GELU)
+    int G0;       // group of a row: g = b*G0 + (G0 > 1 ? p0 : 0)
+    // ---- B operand
+    i64 w_w;    // W: [Np][Kp], zero padded
+    i64 bias_w; // W: [Np]
+    int N, Np;
+    // ---- epilogue
+    int epi, act;             // act: 0 none, 1 exact GELU
+    i64 y, yBatchStride;      // A
+    int ldy;
+    i64 res;                  // A (same indexing as y) or -1
+    i64 scale_w;              // W: per output channel ([Np] for SCALE_RES, [C] for GN_GLU_SCALE_RES) or -1
+    i64 epiStats;             // A: [B*G0][4] for EPI_GN_GLU_SCALE_RES
+    i64 epiW_w, epiB_w;       // W: [Np] GroupNorm affine in packed column order
+    i64 rowstat;              // A: [M][NB][2] partial (sum, sumsq) per row and column block, or -1
+    int NB;                   // number of column blocks writing rowstat (= ceil(Np/BN)); set by engine cfg
+    i64 table_w;              // W: [P0][C] (EPI_GLU freq-embedding add) or -1
+    float tableScale;
+    int Lout, Cout;           // EPI_TRCONV: output positions per (b,p1) row, channels
+    int cfg;                  // tile configuration index (engine)
+};
+
+struct StatsReduce
+{
+    i64 rowstat; // A: [B][R][NB][2]
+    i64 out;     // A: [B*G0][4]
+    int B, R;    // R rows per batch element
+    int NB;
+    int G0;      // G0 > 1: row r belongs to group r % G0; else one group per batch element
+    double count; // elements per group
+    int mode;
+    float eps;
+};
+
+struct Stft
+{
+    i64 mix;  // A: [B][seg][2] interleaved stereo
+    i64 x;    // A: [B][T][2048][4] CaC (re0,im0,re1,im1), un-normalised
+    i64 rowstat;  // A: [B][T][1][2] (sum, sumsq) of the CaC frame (freq z-norm)
+    i64 rowstatT; // A: [B][T][1][2] (sum, sumsq) of raw mix samples [t*1024,(t+1)*1024) x 2ch (time z-norm)
+    int B, T, seg, pad;
+    i64 window, twiddle; // A constants: [4096] hann, [2048][2] exp(-2 pi i k/4096)
+};
+
+struct LayerNorm
+{
+    i64 x, y; // A: [rows][D]
+    int rows, D, rowsPerBatch;
+    i64 w_w, b_w; // W
+    i64 pe;       // A constant [rowsPerBatch][D] added after the affine, or -1
+    float eps;
+};
+
+struct GnApply
+{
+    // v = x; if stats >= 0: v = (v - mean_b)*rstd_b*w[c] + b[c]; if res >= 0: v += res; y = v
+    i64 x, y, res; // A: [B][rows][C]
+    int B, rows, C;
+    i64 stats; // A: [B][4] or -1
+    i64 w_w, b_w;
+};
+
+struct Attention
+{
+    i64 q, k, v, o; // A
+    int ldq, ldk, ldv, ldo;
+    i64 qBatch, kBatch, vBatch, oBatch; // batch strides (elements)
+    int B, Tq, Tk, H, hs;
+    float scale; // 1/sqrt(hs)
+};
+
+struct Istft
+{
+    i64 x;      // A: [B][T][2048][4S] decoder output (normalised domain)
+    i64 stats;  // A: [B][4] z-norm record of the freq branch (mean, scale, std)
+    i64 frames; // A: [B][S][2][T][4096] windowed inverse frames (y * hann)
+    int B, T, S;
+    i64 window, twiddle;
+};
+
+struct Ola
+{
+    i64 frames;  // as Istft
+    i64 xt;      // A: [B][seg][2S] time-branch decoder output (normalised domain)
+    i64 statsT;  // A: [B][4] z-norm record of the time branch
+    i64 wss;     // A constant: [(T+4-1)*1024 + 4096] window sum-square of T+4 frames
+    i64 out;     // A: [B][S][2][seg] planar
+    int B, T, S, seg, pad;
+};
+
+struct Tap
+{
+    i64 off;
+    int shape[4]; // physical dims (batch excluded), unused = 0
+    i64 batchStride;
+};
+
+struct Op
+{
+    int kind;
+    int stream; // 0 = freq branch / main, 1 = time branch (engine may run them concurrently)
+    std::string name;
+    IGemm g;
+    StatsReduce sr;
+    Stft stft;
+    LayerNorm ln;
+    GnApply gn;
+    Attention at;
+    Istft istft;
+    Ola ola;
+    Tap tap;
+};
+
+// geometry of one segment (model.hpp:19-24,618-625 generalised to any length)
+struct Geo
+{
+    i64 seg, le, pad, pad_end, padded, nfr;
+    i64 Lt[5];
+};
+Geo make_geo(i64 seg);
+
+struct PackedModel
+{
+    int n_sources = 4;
+    int dim = 512;
+    int n_tensors = 0;
+    std::vector<float> blob;                       // W space
+    std::vector<std::pair<std::string, i64>> index; // packed array name -> offset
+    i64 find(const std::string &name) const;
+};
+
+// tile configurations of the igemm kernel (engine.cpp instantiates exactly these)
+struct TileCfg
+{
+    int BM, BN;
+};
+static const TileCfg kTileCfgs[] = {
+    {128, 128}, // 0
+    {64, 64},   // 1
+    {128, 96},  // 2
+    {128, 48},  // 3
+    {256, 16},  // 4
+    {128, 32},  // 5
+    {128, 64},  // 6
+};
+static const int kNumTileCfgs = 7;
+int choose_cfg(i64 M, int N, bool paired);
+
+struct Plan
+{
+    int B = 1;
+    Geo geo;
+    int S = 4, D = 512;
+    i64 arenaFloats = 0;
+    std::vector<float> constants; // first `constants.size()` floats of A
+    std::vector<Op> ops;
+    i64 mixOff = 0; // A: [B][seg][2]
+    i64 outOff = 0; // A: [B][S][2][seg]
+};
+
+// model_pack.cpp
+bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err);
+// plan.cpp
+void build_plan(const PackedModel &pm, i64 seg, int B, Plan &plan);
+
+} // namespace dmx
