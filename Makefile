@@ -1,0 +1,35 @@
+# Builds the product library, the CLI and the test-only helpers. gfx950 only.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+CSRC := demucs_cpp_amd/csrc
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
+LIB := demucs_cpp_amd/lib/libdemucs_hip.so
+OBJS := $(addprefix build/,igemm.o fft.o misc.o attention.o api.o plan.o model_pack.o)
+
+all: $(LIB) cli oracle interp
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/plan.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/%.o: $(CSRC)/%.cpp $(CSRC)/kernels.h $(CSRC)/plan.h include/demucs_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p demucs_cpp_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+cli: cli/demucs.cpp.main cli/demucs_ft.cpp.main
+cli/%.cpp.main: cli/%_main.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp cli/wav.hpp
+	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -Wl,-rpath,'$$ORIGIN/../demucs_cpp_amd/lib'
+
+oracle:
+	$(MAKE) -C oracle
+interp:
+	@mkdir -p tests/_build
+	g++ -O2 -march=native -fopenmp -std=c++17 -fPIC -shared -o tests/_build/libcpu_interp.so tests/cpu_interp.cpp
+
+clean:
+	rm -rf build $(LIB) tests/_build cli/*.main
+	$(MAKE) -C oracle clean
+.PHONY: all cli oracle interp clean

@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the HTDemucs-4s per-segment hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+as one rank per GPU by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment, backend "nccl" = RCCL). Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], batched): htdemucs-4s, synthetic dmc4 weights (seed 0),
+synthetic 44.1 kHz stereo 0.1*N(0,1), segments of 343980 samples (7.8 s), fp32 arithmetic.
+One step on every rank = `--batch` segments, already resident in HBM, through the whole hot
+path (STFT -> encoders -> cross-transformer -> decoders -> ISTFT, C ABI
+dmx_segment_infer_device). This is the embarrassingly parallel segment loop of
+src/model_apply.cpp:189-235: ranks own disjoint segments (weak scaling, no collective inside the
+hot path). The one real exchange step of the track path - gathering the per-segment outputs
+to the root before overlap-add (north_star) - is part of every step when N > 1
+(RCCL gather over xGMI), followed by the root's triangle-weighted overlap-add of all N*batch
+segments (dmx_track_overlap_add_device); with N = 1 the overlap-add alone runs.
+value = audio seconds pushed through the hot path per wall second = N*batch*7.8*K / T, T = max
+over ranks of the barrier-bracketed wall time of the K timed steps.
+
+Extra objects on the JSON line:
+  roofline     : dominant kernel (by device time) measured live with HIP events on the stream
+                 it runs on (dmx_debug_profile), algorithmic FLOPs / duration vs the fp32 MFMA
+                 peak 157.3 TFLOP/s (MI355X_MICROARCH.md); traffic = PMC HBM bytes (null unless
+                 profiles/ holds a counter pass)
+  cpu_baseline : the CPU oracle (oracle/, a from-scratch port of the reference algorithm;
+                 the reference itself needs Eigen and cannot be built here) timed on this box's
+                 host cores on ONE full segment, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SEG = 343980
+SEG_SECONDS = 7.8
+PEAK_TFLOPS_FP32_MFMA = 157.3
+MODEL_FLOPS_4S = 340.2e9  # algorithmic FLOPs per segment (SURVEY.md §8d / BASELINE.md §3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "4")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from demucs_cpp_amd import binding as dmx
+    from demucs_cpp_amd.weights import write_synthetic_model
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    S = 4
+    tmpdir = os.environ.get("TMPDIR", "/tmp")
+    mpath = os.path.join(tmpdir, f"dmx_bench_model_4s_{os.getpid()}.bin")
+    write_synthetic_model(mpath, 4, 0)
+    model = dmx.Model(mpath, local_rank)
+    os.remove(mpath)
+    ctx = dmx.Context(model, SEG, B)
+
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    mix = (0.1 * torch.randn((B, SEG, 2), generator=gen)).cuda()  # interleaved stereo, resident in HBM
+    out = torch.zeros((B, S, 2, SEG), device="cuda")
+    nseg_total = world * B
+    stride = int((1 - 0.25) * SEG)
+    # the N*B segments of one step form a stretch of a track whose segment loop
+    # (`for offset < len; offset += stride`) has exactly nseg_total iterations: len = nseg*stride
+    n_track = nseg_total * stride - 22050  # shift offset 0: len = n + 22050
+    d_stats = torch.tensor([0.0, 1.0, 0.0, 0.0], device="cuda")
+    gathered = None
+    track_out = None
+    if rank == 0:
+        gathered = [torch.zeros_like(out) for _ in range(world)]
+        track_out = torch.zeros((S, 2, n_track), device="cuda")
+
+    def step():
+        ctx.segment_device(mix.data_ptr(), out.data_ptr(), B)
+        ctx.synchronize()  # the library runs on its own stream; hand over to torch's stream / RCCL
+        if world > 1:
+            dist.gather(out, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                allseg = torch.cat(gathered, dim=0)
+        else:
+            allseg = out
+        if rank == 0:
+            torch.cuda.current_stream().synchronize()
+            ctx.track_overlap_add_device(allseg.data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), track_out.data_ptr())
+            ctx.synchronize()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = bool(torch.isfinite(out).all().item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        prof = ctx.profile(B, 3)
+        by_kernel = {}
+        for nm, k, ms, fl, by in prof:
+            d = by_kernel.setdefault(k, [0.0, 0.0, 0.0, 0])
+            d[0] += ms
+            d[1] += fl
+            d[2] += by
+            d[3] += 1
+        dom = max(by_kernel.items(), key=lambda kv: kv[1][0])
+        kname, (ms, fl, by, cnt) = dom
+        tot_ms = sum(v[0] for v in by_kernel.values())
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": None,
+            "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
+            "algorithmic_flops_per_launch": fl / cnt, "algorithmic_bytes_per_launch": by / cnt,
+            "kernel_share_of_device_time": round(ms / tot_ms, 3),
+            "sum_of_kernel_ms_per_step": round(tot_ms, 3),
+            "whole_path_tflops": round(MODEL_FLOPS_4S * B / (tot_ms * 1e-3) / 1e12, 2),
+        }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as orc  # test infrastructure, timed here only as the reported CPU baseline
+
+        mpath2 = os.path.join(tmpdir, f"dmx_bench_model_cpu_{os.getpid()}.bin")
+        write_synthetic_model(mpath2, 4, 0)
+        om = orc.OracleModel(mpath2)
+        os.remove(mpath2)
+        cm = np.ascontiguousarray(mix[0].cpu().numpy().T)
+        t0 = time.perf_counter()
+        om.segment(cm)
+        dt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(SEG_SECONDS / dt, 4), "unit": "audio-sec/s", "cores": int(orc.lib().orc_num_threads()),
+                        "kind": "port", "sample": f"1 full 7.8 s segment (343980 samples), htdemucs-4s synthetic weights, {dt:.1f} s wall",
+                        "published_reference_context": "0.385x RT on 16 Zen3 cores, real weights (.github/PERFORMANCE.md:42-47)"}
+        om.close()
+
+    if rank == 0:
+        audio_s = nseg_total * SEG_SECONDS * args.steps
+        line = {
+            "metric": "audio-sec/s (xRT) htdemucs-4s 44.1kHz stereo, per-segment hot path",
+            "value": round(audio_s / elapsed, 2),
+            "unit": "audio-sec/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "htdemucs-4s f16-weights, 343980-sample segments, fp32 MFMA compute, "
+                                   f"{B} segments/GPU/step resident in HBM + root overlap-add"
+                                   + (" + RCCL gather to root" if world > 1 else ""),
+                       "segments_per_gpu_per_step": B, "segment_samples": SEG, "audio_seconds_per_segment": SEG_SECONDS,
+                       "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
+                       "parallelism": f"segment-sharded x{world}"},
+        }
+        if roofline:
+            line["roofline"] = roofline
+        if cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+// demucs.cpp.main — single-model CLI with the reference's argv contract and output naming
+// (/root/reference/cli-apps/demucs.cpp:107-232): demucs.cpp.main <model file> <wav file> <out dir>
+// -> <out dir>/target_{i}_{drums|bass|other|vocals|guitar|piano}.wav (stereo float32).
+// Environment: DMX_DEVICE (GPU index), DMX_SHIFT_OFFSET (fixed shift instead of rand()),
+// DMX_BATCH (segments in flight).
+#include <filesystem>
+#include <iomanip>
+
+#include "wav.hpp"
+
+using namespace demucscpp;
+
+int main(int argc, const char **argv)
+{
+    if (argc != 4)
+    {
+        std::cerr << "Usage: " << argv[0] << " <model file> <wav file> <out dir>" << std::endl;
+        exit(1);
+    }
+    std::cout << "demucs.cpp Main driver program (MI355X HIP path)" << std::endl;
+    std::string model_file = argv[1], wav_file = argv[2], out_dir = argv[3];
+    StereoMatrix audio;
+    if (!wavio::load_audio_file(wav_file, audio))
+        exit(1);
+    demucs_model model;
+    auto ret = load_demucs_model(model_file, &model);
+    std::cout << "demucs_model_load returned " << (ret ? "true" : "false") << std::endl;
+    if (!ret)
+    {
+        std::cerr << "Error loading model" << std::endl;
+        exit(1);
+    }
+    const int nb_sources = model.is_4sources ? 4 : 6;
+    std::cout << "Starting Demucs (" << nb_sources << "-source) inference" << std::endl;
+    std::cout << std::fixed << std::setprecision(3);
+    ProgressCallback cb = [](float progress, const std::string &msg) {
+        std::cout << "(" << std::setw(3) << std::setfill(' ') << progress * 100.0f << "%) " << msg << std::endl;
+    };
+    StemTensor out = demucs_inference(model, audio, cb);
+    static const char *names[6] = {"drums", "bass", "other", "vocals", "guitar", "piano"};
+    std::filesystem::path p = out_dir;
+    std::filesystem::create_directories(p);
+    std::vector<float> wave((size_t)(2 * audio.cols()));
+    for (int target = 0; target < nb_sources; ++target)
+    {
+        auto p_target = p / ("target_" + std::to_string(target) + "_" + names[target] + ".wav");
+        std::cout << "Writing wav file " << p_target << std::endl;
+        for (int64_t i = 0; i < audio.cols(); ++i)
+        {
+            wave[(size_t)(2 * i)] = out(target, 0, i);
+            wave[(size_t)(2 * i + 1)] = out(target, 1, i);
+        }
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string()))
+        {
+            std::cerr << "Error writing " << p_target << std::endl;
+            exit(1);
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,158 @@
+// wav.hpp — minimal RIFF/WAVE I/O for the CLI drivers (the reference uses libnyquist,
+// cli-apps/demucs.cpp:21-105; absent here). Reads PCM 16/24/32-bit and IEEE float32,
+// skips unknown chunks (e.g. the LIST chunk of test/data/gspi_stereo*.wav), 44.1 kHz
+// mono (duplicated to both channels, demucs.cpp:56-64) or stereo only; writes stereo
+// float32 like the reference (PCM_FLT, demucs.cpp:100-102).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "demucscpp_hip.hpp"
+
+namespace wavio
+{
+inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix &out)
+{
+    FILE *f = fopen(filename.c_str(), "rb");
+    if (!f)
+    {
+        std::cerr << "[ERROR] cannot open " << filename << std::endl;
+        return false;
+    }
+    std::vector<uint8_t> b;
+    {
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        b.resize((size_t)sz);
+        if (fread(b.data(), 1, (size_t)sz, f) != (size_t)sz)
+        {
+            fclose(f);
+            return false;
+        }
+        fclose(f);
+    }
+    if (b.size() < 12 || memcmp(b.data(), "RIFF", 4) != 0 || memcmp(b.data() + 8, "WAVE", 4) != 0)
+    {
+        std::cerr << "[ERROR] not a RIFF/WAVE file: " << filename << std::endl;
+        return false;
+    }
+    uint16_t tag = 0, nch = 0, bits = 0;
+    uint32_t rate = 0;
+    const uint8_t *data = nullptr;
+    size_t dataLen = 0;
+    size_t pos = 12;
+    while (pos + 8 <= b.size())
+    {
+        uint32_t sz;
+        memcpy(&sz, &b[pos + 4], 4);
+        if (memcmp(&b[pos], "fmt ", 4) == 0 && pos + 8 + 16 <= b.size())
+        {
+            memcpy(&tag, &b[pos + 8], 2);
+            memcpy(&nch, &b[pos + 10], 2);
+            memcpy(&rate, &b[pos + 12], 4);
+            memcpy(&bits, &b[pos + 22], 2);
+            if (tag == 0xFFFE && sz >= 26) // WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first 2 bytes
+                memcpy(&tag, &b[pos + 8 + 24], 2);
+        }
+        else if (memcmp(&b[pos], "data", 4) == 0)
+        {
+            data = &b[pos + 8];
+            dataLen = std::min((size_t)sz, b.size() - pos - 8);
+        }
+        pos += 8 + (size_t)sz + (sz & 1);
+    }
+    if (!data || nch == 0)
+    {
+        std::cerr << "[ERROR] malformed wav: " << filename << std::endl;
+        return false;
+    }
+    if ((int)rate != demucscpp::SUPPORTED_SAMPLE_RATE)
+    {
+        std::cerr << "[ERROR] demucs.cpp only supports the following sample rate (Hz): " << demucscpp::SUPPORTED_SAMPLE_RATE
+                  << std::endl; // cli-apps/demucs.cpp:30-36
+        return false;
+    }
+    if (nch != 1 && nch != 2)
+    {
+        std::cerr << "[ERROR] demucs.cpp only supports mono and stereo audio" << std::endl; // :42-48
+        return false;
+    }
+    const size_t bps = bits / 8;
+    const size_t N = dataLen / (bps * nch);
+    out = demucscpp::StereoMatrix((int64_t)N);
+    auto sample = [&](size_t idx) -> float {
+        const uint8_t *p = data + idx * bps;
+        if (tag == 3 && bits == 32)
+        {
+            float v;
+            memcpy(&v, p, 4);
+            return v;
+        }
+        if (tag == 1 && bits == 16)
+        {
+            int16_t v;
+            memcpy(&v, p, 2);
+            return (float)v / 32768.0f;
+        }
+        if (tag == 1 && bits == 24)
+        {
+            int32_t v = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24) >> 8;
+            return (float)v / 8388608.0f;
+        }
+        if (tag == 1 && bits == 32)
+        {
+            int32_t v;
+            memcpy(&v, p, 4);
+            return (float)v / 2147483648.0f;
+        }
+        return 0.0f;
+    };
+    if (!((tag == 3 && bits == 32) || (tag == 1 && (bits == 16 || bits == 24 || bits == 32))))
+    {
+        std::cerr << "[ERROR] unsupported wav encoding (tag " << tag << ", " << bits << " bits)" << std::endl;
+        return false;
+    }
+    std::cout << "Input samples: " << N << std::endl;
+    std::cout << "Length in seconds: " << (double)N / rate << std::endl;
+    std::cout << "Number of channels: " << nch << std::endl;
+    for (size_t i = 0; i < N; ++i)
+    {
+        float l = sample(i * nch), r = nch == 2 ? sample(i * nch + 1) : l;
+        out(0, (int64_t)i) = l;
+        out(1, (int64_t)i) = r;
+    }
+    return true;
+}
+
+// stereo float32 WAV; `interleaved` = 2*N floats
+inline bool write_audio_file(const float *interleaved, int64_t N, const std::string &filename)
+{
+    FILE *f = fopen(filename.c_str(), "wb");
+    if (!f)
+        return false;
+    const uint32_t dataBytes = (uint32_t)(N * 2 * 4), rate = 44100, byteRate = rate * 8, fmtLen = 16;
+    const uint32_t riffLen = 4 + (8 + fmtLen) + (8 + dataBytes);
+    const uint16_t tag = 3, nch = 2, align = 8, bits = 32;
+    fwrite("RIFF", 1, 4, f);
+    fwrite(&riffLen, 4, 1, f);
+    fwrite("WAVE", 1, 4, f);
+    fwrite("fmt ", 1, 4, f);
+    fwrite(&fmtLen, 4, 1, f);
+    fwrite(&tag, 2, 1, f);
+    fwrite(&nch, 2, 1, f);
+    fwrite(&rate, 4, 1, f);
+    fwrite(&byteRate, 4, 1, f);
+    fwrite(&align, 2, 1, f);
+    fwrite(&bits, 2, 1, f);
+    fwrite("data", 1, 4, f);
+    fwrite(&dataBytes, 4, 1, f);
+    fwrite(interleaved, 4, (size_t)(N * 2), f);
+    fclose(f);
+    return true;
+}
+} // namespace wavio

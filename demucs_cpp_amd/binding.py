@@ -1,0 +1,206 @@
+"""ctypes binding of the C ABI in include/demucs_hip.h (libdemucs_hip.so, built in-tree
+by `make` / __graft_entry__.build()).
+
+This module is plumbing for tests and bench.py; the product is the shared library.
+There is deliberately NO fallback: if the library is missing, or no GPU is usable, the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "demucs_cpp_amd", "lib", "libdemucs_hip.so")
+
+LAYOUT_EIGEN = 0
+LAYOUT_PLANAR = 1
+SEGMENT_SAMPLES = 343980
+MAX_SHIFT = 22050
+
+# every symbol include/demucs_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "dmx_last_error", "dmx_device_count", "dmx_model_load", "dmx_model_free", "dmx_model_n_sources",
+    "dmx_model_n_tensors", "dmx_model_device", "dmx_ctx_create", "dmx_ctx_free", "dmx_ctx_segment_samples",
+    "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_segment_infer",
+    "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
+    "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
+    "dmx_debug_profile",
+]
+
+_lib = None
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_float, ctypes.c_char_p, ctypes.c_void_p)
+
+
+class DmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[dmx error {code}] {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `make` or __graft_entry__.build() (no fallback exists)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64, ci, fp = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+        L.dmx_last_error.restype = ctypes.c_char_p
+        L.dmx_model_load.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+        L.dmx_model_free.argtypes = [vp]
+        for f in ("dmx_model_n_sources", "dmx_model_n_tensors", "dmx_model_device"):
+            getattr(L, f).argtypes = [vp]
+        L.dmx_ctx_create.argtypes = [vp, i64, ci, ctypes.POINTER(vp)]
+        L.dmx_ctx_free.argtypes = [vp]
+        L.dmx_ctx_segment_samples.argtypes = [vp]
+        L.dmx_ctx_segment_samples.restype = i64
+        L.dmx_ctx_max_batch.argtypes = [vp]
+        L.dmx_ctx_arena_bytes.argtypes = [vp]
+        L.dmx_ctx_arena_bytes.restype = i64
+        L.dmx_ctx_synchronize.argtypes = [vp]
+        L.dmx_segment_infer.argtypes = [vp, fp, fp, ci]
+        L.dmx_segment_infer_device.argtypes = [vp, fp, fp, ci]
+        L.dmx_track_infer.argtypes = [vp, fp, i64, ci, fp, ci, vp, vp]
+        L.dmx_track_geometry.argtypes = [vp, i64, ci, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(i64)]
+        L.dmx_track_stats_device.argtypes = [vp, fp, i64, fp]
+        L.dmx_track_gather_device.argtypes = [vp, fp, i64, fp, ci, vp, ci, fp]
+        L.dmx_track_overlap_add_device.argtypes = [vp, fp, ci, i64, ci, fp, fp, ci]
+        L.dmx_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, fp]
+        L.dmx_debug_n_ops.argtypes = [vp]
+        L.dmx_debug_profile.argtypes = [vp, ci, ci, ctypes.c_char_p, ci]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise DmxError(rc, lib().dmx_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return lib().dmx_device_count()
+
+
+class Model:
+    """demucscpp::demucs_model + load_demucs_model (src/model.hpp:285-554, :649)."""
+
+    def __init__(self, path: str, device: int = 0):
+        self.h = ctypes.c_void_p()
+        _chk(lib().dmx_model_load(path.encode(), device, ctypes.byref(self.h)))
+        self.n_sources = lib().dmx_model_n_sources(self.h)
+        self.n_tensors = lib().dmx_model_n_tensors(self.h)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().dmx_model_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, model: Model, segment_samples: int = 0, max_batch: int = 1):
+        self.model = model
+        self.h = ctypes.c_void_p()
+        _chk(lib().dmx_ctx_create(model.h, segment_samples, max_batch, ctypes.byref(self.h)))
+        self.seg = lib().dmx_ctx_segment_samples(self.h)
+        self.max_batch = max_batch
+        self.S = model.n_sources
+
+    def close(self):
+        if self.h:
+            lib().dmx_ctx_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def arena_bytes(self) -> int:
+        return lib().dmx_ctx_arena_bytes(self.h)
+
+    def synchronize(self):
+        _chk(lib().dmx_ctx_synchronize(self.h))
+
+    # ---- host-pointer API
+    def segment(self, mix: np.ndarray) -> np.ndarray:
+        """mix (2, seg) planar -> (S, 2, seg) planar; demucscpp::model_inference."""
+        mix = np.ascontiguousarray(mix, np.float32)
+        assert mix.shape == (2, self.seg)
+        out = np.zeros((self.S, 2, self.seg), np.float32)
+        _chk(lib().dmx_segment_infer(self.h, mix.ctypes.data, out.ctypes.data, LAYOUT_PLANAR))
+        return out
+
+    def segment_eigen(self, mix_interleaved: np.ndarray) -> np.ndarray:
+        """Eigen memory images: in (seg, 2) interleaved, out flat image of Tensor3dXf(S,2,seg)."""
+        mix = np.ascontiguousarray(mix_interleaved, np.float32)
+        out = np.zeros(self.S * 2 * self.seg, np.float32)
+        _chk(lib().dmx_segment_infer(self.h, mix.ctypes.data, out.ctypes.data, LAYOUT_EIGEN))
+        return out
+
+    def track(self, audio: np.ndarray, shift_offset: int, progress=None) -> np.ndarray:
+        """audio (2, n) planar -> (S, 2, n); demucscpp::demucs_inference."""
+        audio = np.ascontiguousarray(audio, np.float32)
+        n = audio.shape[1]
+        out = np.zeros((self.S, 2, n), np.float32)
+        cb = PROGRESS_FN(lambda p, m, u: progress(p, m.decode())) if progress else None
+        cbp = ctypes.cast(cb, ctypes.c_void_p) if cb else None
+        _chk(lib().dmx_track_infer(self.h, audio.ctypes.data, n, shift_offset, out.ctypes.data, LAYOUT_PLANAR, cbp, None))
+        return out
+
+    def track_geometry(self, n: int, shift_offset: int) -> Tuple[int, int, int]:
+        ln, st, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _chk(lib().dmx_track_geometry(self.h, n, shift_offset, ctypes.byref(ln), ctypes.byref(ns), ctypes.byref(st)))
+        return ln.value, ns.value, st.value
+
+    # ---- device-pointer API (raw addresses, e.g. torch.Tensor.data_ptr())
+    def segment_device(self, d_mix: int, d_out: int, batch: int):
+        _chk(lib().dmx_segment_infer_device(self.h, d_mix, d_out, batch))
+
+    def track_stats_device(self, d_audio: int, n: int, d_stats: int):
+        _chk(lib().dmx_track_stats_device(self.h, d_audio, n, d_stats))
+
+    def track_gather_device(self, d_audio: int, n: int, d_stats: int, shift_offset: int, seg_idx: List[int], d_mix: int):
+        arr = (ctypes.c_int * len(seg_idx))(*seg_idx)
+        _chk(lib().dmx_track_gather_device(self.h, d_audio, n, d_stats, shift_offset, arr, len(seg_idx), d_mix))
+
+    def track_overlap_add_device(self, d_seg_out: int, n_segments: int, n: int, shift_offset: int, d_stats: int, d_out: int,
+                                 layout: int = LAYOUT_PLANAR):
+        _chk(lib().dmx_track_overlap_add_device(self.h, d_seg_out, n_segments, n, shift_offset, d_stats, d_out, layout))
+
+    # ---- debug
+    def tap(self, name: str) -> Optional[np.ndarray]:
+        shape = (ctypes.c_int64 * 8)()
+        nd = lib().dmx_debug_tap(self.h, name.encode(), shape, None)
+        if nd < 0:
+            return None
+        shp = [shape[i] for i in range(nd)]
+        out = np.zeros(shp, np.float32)
+        lib().dmx_debug_tap(self.h, name.encode(), shape, out.ctypes.data)
+        return out
+
+    def profile(self, batch: int = 1, reps: int = 3):
+        """[(op name, kernel, ms per launch, algorithmic flops, algorithmic bytes)]"""
+        cap = 1 << 17
+        buf = ctypes.create_string_buffer(cap)
+        n = lib().dmx_debug_profile(self.h, batch, reps, buf, cap)
+        if n < 0:
+            raise RuntimeError("profile failed")
+        rows = []
+        for ln in buf.value.decode().split("\n"):
+            if not ln:
+                continue
+            nm, k, ms, fl, by = ln.split("\t")
+            rows.append((nm, k, float(ms), float(fl), float(by)))
+        return rows

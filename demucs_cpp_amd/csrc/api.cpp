@@ -1,0 +1,635 @@
+// api.cpp — C ABI (include/demucs_hip.h) + plan executor for the MI355X HTDemucs path.
+//
+// Host-side restatement of the reference's entry points (citations in demucs_hip.h):
+//   load_demucs_model  -> dmx_model_load        (src/model_load.cpp:50)
+//   model_inference    -> dmx_segment_infer*    (src/model_inference.cpp:48)
+//   demucs_inference   -> dmx_track_infer       (src/model_apply.cpp:60-288)
+// No CPU fallback exists: without a usable HIP device every compute entry point fails.
+#include "../../include/demucs_hip.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace dmx;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                          \
+    do                                                                                                        \
+    {                                                                                                         \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(DMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct dmx_model
+{
+    PackedModel pm;
+    float *dW = nullptr;
+    int device = 0;
+};
+
+struct dmx_ctx
+{
+    const dmx_model *m = nullptr;
+    i64 seg = 0;
+    int maxBatch = 1;
+    std::map<int, std::unique_ptr<Plan>> plans;
+    float *dA = nullptr;
+    i64 arenaFloats = 0;
+    hipStream_t stream = nullptr;
+    int lastBatch = 0;
+    // track-level scratch
+    double *dPartials = nullptr;
+    int *dSegIdx = nullptr;
+    static const int kStatBlocks = 256;
+};
+
+extern "C" const char *dmx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int dmx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **out)
+{
+    if (!model_file || !out)
+        return fail(DMX_ERR_ARG, "dmx_model_load: null argument");
+    *out = nullptr;
+    auto m = std::make_unique<dmx_model>();
+    std::string err;
+    if (!load_and_pack(model_file, m->pm, err))
+    {
+        bool io = err.find("failed to open") != std::string::npos || err.find("truncated") != std::string::npos;
+        fprintf(stderr, "%s\n", err.c_str()); // the reference loader also reports on stderr
+        return fail(io ? DMX_ERR_IO : DMX_ERR_FORMAT, "%s", err.c_str());
+    }
+    int ndev = dmx_device_count();
+    if (ndev <= 0)
+        return fail(DMX_ERR_NO_DEVICE, "dmx_model_load: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(DMX_ERR_ARG, "dmx_model_load: device %d out of range (have %d)", device, ndev);
+    m->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = m.release();
+    return DMX_OK;
+}
+
+extern "C" void dmx_model_free(dmx_model *m)
+{
+    if (!m)
+        return;
+    if (m->dW)
+    {
+        (void)hipSetDevice(m->device);
+        (void)hipFree(m->dW);
+    }
+    delete m;
+}
+extern "C" int dmx_model_n_sources(const dmx_model *m) { return m ? m->pm.n_sources : 0; }
+extern "C" int dmx_model_n_tensors(const dmx_model *m) { return m ? m->pm.n_tensors : 0; }
+extern "C" int dmx_model_device(const dmx_model *m) { return m ? m->device : -1; }
+
+static Plan *get_plan(dmx_ctx *c, int batch)
+{
+    auto it = c->plans.find(batch);
+    if (it != c->plans.end())
+        return it->second.get();
+    auto p = std::make_unique<Plan>();
+    build_plan(c->m->pm, c->seg, batch, *p);
+    Plan *raw = p.get();
+    c->plans[batch] = std::move(p);
+    return raw;
+}
+
+extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out)
+{
+    if (!m || !out || max_batch < 1 || max_batch > 64)
+        return fail(DMX_ERR_ARG, "dmx_ctx_create: invalid argument");
+    *out = nullptr;
+    if (segment_samples == 0)
+        segment_samples = DMX_SEGMENT_SAMPLES;
+    if (segment_samples < 4096 || segment_samples % 2 != 0)
+        return fail(DMX_ERR_ARG, "dmx_ctx_create: segment_samples must be even and >= 4096");
+    auto c = std::make_unique<dmx_ctx>();
+    c->m = m;
+    c->seg = segment_samples;
+    c->maxBatch = max_batch;
+    HIPCHK(hipSetDevice(m->device));
+    Plan *p = get_plan(c.get(), max_batch);
+    c->arenaFloats = p->arenaFloats;
+    HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float)));
+    HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float)));
+    HIPCHK(hipMemcpy(c->dA, p->constants.data(), p->constants.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
+    HIPCHK(hipMalloc((void **)&c->dSegIdx, sizeof(int) * 4096));
+    *out = c.release();
+    return DMX_OK;
+}
+
+extern "C" void dmx_ctx_free(dmx_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->m->device);
+    if (c->stream)
+    {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->dA)
+        (void)hipFree(c->dA);
+    if (c->dPartials)
+        (void)hipFree(c->dPartials);
+    if (c->dSegIdx)
+        (void)hipFree(c->dSegIdx);
+    delete c;
+}
+extern "C" int64_t dmx_ctx_segment_samples(const dmx_ctx *c) { return c ? c->seg : 0; }
+extern "C" int dmx_ctx_max_batch(const dmx_ctx *c) { return c ? c->maxBatch : 0; }
+extern "C" int64_t dmx_ctx_arena_bytes(const dmx_ctx *c) { return c ? c->arenaFloats * 4 : 0; }
+extern "C" int dmx_ctx_synchronize(dmx_ctx *c)
+{
+    if (!c)
+        return fail(DMX_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DMX_OK;
+}
+
+// --------------------------------------------------------------------------- executor
+static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s)
+{
+    float *A = c->dA;
+    const float *W = c->m->dW;
+    auto a = [&](i64 off) -> float * { return off >= 0 ? A + off : nullptr; };
+    auto w = [&](i64 off) -> const float * { return off >= 0 ? W + off : nullptr; };
+    switch (op.kind)
+    {
+    case OP_IGEMM:
+    {
+        const IGemm &g = op.g;
+        GemmArgs k;
+        k.X = a(g.x), k.xBS = g.xBatchStride;
+        k.B = g.B, k.P1 = g.P1, k.P0 = g.P0, k.L1 = g.L1, k.L0 = g.L0, k.Cin = g.Cin;
+        k.S1 = g.S1, k.stride1 = g.stride1, k.dil1 = g.dil1, k.pad1 = g.pad1;
+        k.seg0 = g.seg0, k.stride0 = g.stride0, k.pad0 = g.pad0, k.K = g.K, k.Kp = g.Kp;
+        k.pro = g.pro, k.proStats = a(g.proStats), k.proW = w(g.proW_w), k.proB = w(g.proB_w), k.G0 = g.G0;
+        k.Wt = w(g.w_w), k.bias = w(g.bias_w), k.N = g.N, k.Np = g.Np;
+        k.epi = g.epi, k.act = g.act, k.Y = a(g.y), k.yBS = g.yBatchStride, k.ldy = g.ldy;
+        k.res = a(g.res), k.scale = w(g.scale_w), k.epiStats = a(g.epiStats), k.epiW = w(g.epiW_w), k.epiB = w(g.epiB_w);
+        k.rowstat = a(g.rowstat), k.NB = g.NB, k.table = w(g.table_w), k.tableScale = g.tableScale;
+        k.Lout = g.Lout, k.Cout = g.Cout;
+        k.M = (i64)g.B * g.P1 * g.P0;
+        launch_igemm(g.cfg, k, s);
+        break;
+    }
+    case OP_STATS_REDUCE:
+    {
+        const StatsReduce &r = op.sr;
+        launch_stats_reduce(ReduceArgs{a(r.rowstat), a(r.out), r.B, r.R, r.NB, r.G0, r.count, r.mode, r.eps}, s);
+        break;
+    }
+    case OP_STFT:
+    {
+        const Stft &t = op.stft;
+        launch_stft(StftArgs{a(t.mix), a(t.x), a(t.rowstat), a(t.rowstatT), t.B, t.T, t.seg, t.pad, a(t.window), a(t.twiddle)}, s);
+        break;
+    }
+    case OP_LAYERNORM:
+    {
+        const LayerNorm &l = op.ln;
+        launch_layernorm(LnArgs{a(l.x), a(l.y), l.rows, l.D, l.rowsPerBatch, w(l.w_w), w(l.b_w), a(l.pe), l.eps}, s);
+        break;
+    }
+    case OP_GN_APPLY:
+    {
+        const GnApply &g = op.gn;
+        launch_gn_apply(GnArgs{a(g.x), a(g.y), a(g.res), g.B, g.rows, g.C, a(g.stats), w(g.w_w), w(g.b_w)}, s);
+        break;
+    }
+    case OP_ATTENTION:
+    {
+        const Attention &t = op.at;
+        launch_attention(AttnArgs{a(t.q), a(t.k), a(t.v), a(t.o), t.ldq, t.ldk, t.ldv, t.ldo, t.qBatch, t.kBatch, t.vBatch,
+                                  t.oBatch, t.B, t.Tq, t.Tk, t.H, t.hs, t.scale},
+                         s);
+        break;
+    }
+    case OP_ISTFT:
+    {
+        const Istft &t = op.istft;
+        launch_istft(IstftArgs{a(t.x), a(t.stats), a(t.frames), t.B, t.T, t.S, a(t.window), a(t.twiddle)}, s);
+        break;
+    }
+    case OP_OLA:
+    {
+        const Ola &o = op.ola;
+        launch_ola(OlaArgs{a(o.frames), a(o.xt), a(o.statsT), a(o.wss), a(o.out), o.B, o.T, o.S, o.seg, o.pad}, s);
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+static int run_plan(dmx_ctx *c, int batch)
+{
+    Plan *p = get_plan(c, batch);
+    if (p->arenaFloats > c->arenaFloats)
+        return fail(DMX_ERR_ARG, "internal: plan for batch %d exceeds the arena", batch);
+    for (const Op &op : p->ops)
+        launch_op(c, op, c->stream);
+    c->lastBatch = batch;
+    HIPCHK(hipGetLastError());
+    return DMX_OK;
+}
+
+extern "C" int dmx_segment_infer_device(dmx_ctx *c, const float *d_mix, float *d_out, int batch)
+{
+    if (!c || !d_mix || !d_out || batch < 1 || batch > c->maxBatch)
+        return fail(DMX_ERR_ARG, "dmx_segment_infer_device: invalid argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    Plan *p = get_plan(c, batch);
+    const int S = c->m->pm.n_sources;
+    HIPCHK(hipMemcpyAsync(c->dA + p->mixOff, d_mix, sizeof(float) * (size_t)batch * c->seg * 2, hipMemcpyDeviceToDevice,
+                          c->stream));
+    int rc = run_plan(c, batch);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(d_out, c->dA + p->outOff, sizeof(float) * (size_t)batch * S * 2 * c->seg, hipMemcpyDeviceToDevice,
+                          c->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmx_segment_infer(dmx_ctx *c, const float *mix, float *out, int layout)
+{
+    if (!c || !mix || !out)
+        return fail(DMX_ERR_ARG, "dmx_segment_infer: null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    Plan *p = get_plan(c, 1);
+    const int S = c->m->pm.n_sources;
+    const i64 seg = c->seg;
+    std::vector<float> tmp;
+    const float *src = mix;
+    if (layout == DMX_LAYOUT_PLANAR)
+    {
+        tmp.resize((size_t)(2 * seg));
+        for (i64 i = 0; i < seg; ++i)
+        {
+            tmp[(size_t)(2 * i)] = mix[i];
+            tmp[(size_t)(2 * i + 1)] = mix[seg + i];
+        }
+        src = tmp.data();
+    }
+    else if (layout != DMX_LAYOUT_EIGEN)
+        return fail(DMX_ERR_ARG, "dmx_segment_infer: unknown layout %d", layout);
+    HIPCHK(hipMemcpyAsync(c->dA + p->mixOff, src, sizeof(float) * (size_t)(2 * seg), hipMemcpyHostToDevice, c->stream));
+    int rc = run_plan(c, 1);
+    if (rc)
+        return rc;
+    std::vector<float> planar((size_t)(S * 2 * seg));
+    HIPCHK(hipMemcpyAsync(planar.data(), c->dA + p->outOff, sizeof(float) * planar.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (layout == DMX_LAYOUT_PLANAR)
+        std::memcpy(out, planar.data(), sizeof(float) * planar.size());
+    else
+        for (int s = 0; s < S; ++s)
+            for (int ch = 0; ch < 2; ++ch)
+                for (i64 i = 0; i < seg; ++i)
+                    out[s + (i64)S * (ch + 2 * i)] = planar[(size_t)((s * 2 + ch) * seg + i)];
+    return DMX_OK;
+}
+
+// --------------------------------------------------------------------------- track level
+extern "C" int dmx_track_geometry(const dmx_ctx *c, int64_t n, int shift_offset, int64_t *shifted_len, int *n_segments,
+                                  int64_t *stride)
+{
+    if (!c || n <= 0 || shift_offset < 0 || shift_offset >= DMX_MAX_SHIFT)
+        return fail(DMX_ERR_ARG, "dmx_track_geometry: invalid argument");
+    // shifted_audio length = length + max_shift - offset (model_apply.cpp:119-120);
+    // stride = (int)((1 - OVERLAP) * segment) (:162); loop `offset += stride` (:189)
+    const i64 len = n + DMX_MAX_SHIFT - shift_offset;
+    const i64 st = (i64)((1.0f - 0.25f) * (float)c->seg);
+    if (shifted_len)
+        *shifted_len = len;
+    if (stride)
+        *stride = st;
+    if (n_segments)
+        *n_segments = (int)((len + st - 1) / st);
+    return DMX_OK;
+}
+
+extern "C" int dmx_track_stats_device(dmx_ctx *c, const float *d_audio, int64_t n, float *d_stats)
+{
+    if (!c || !d_audio || !d_stats || n < 2)
+        return fail(DMX_ERR_ARG, "dmx_track_stats_device: invalid argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    launch_track_stats(d_audio, n, c->dPartials, dmx_ctx::kStatBlocks, c->stream);
+    launch_track_stats_final(c->dPartials, dmx_ctx::kStatBlocks, n, d_stats, c->stream);
+    HIPCHK(hipGetLastError());
+    return DMX_OK;
+}
+
+extern "C" int dmx_track_gather_device(dmx_ctx *c, const float *d_audio, int64_t n, const float *d_stats, int shift_offset,
+                                       const int *seg_idx, int n_idx, float *d_mix)
+{
+    if (!c || !d_audio || !d_stats || !seg_idx || !d_mix || n_idx < 1 || n_idx > 4096)
+        return fail(DMX_ERR_ARG, "dmx_track_gather_device: invalid argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    i64 len, stride;
+    int nseg;
+    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
+    if (rc)
+        return rc;
+    for (int i = 0; i < n_idx; ++i)
+        if (seg_idx[i] < 0 || seg_idx[i] >= nseg)
+            return fail(DMX_ERR_ARG, "dmx_track_gather_device: segment index %d out of range", seg_idx[i]);
+    HIPCHK(hipStreamSynchronize(c->stream)); // dSegIdx may still be in use by a previous gather
+    HIPCHK(hipMemcpyAsync(c->dSegIdx, seg_idx, sizeof(int) * (size_t)n_idx, hipMemcpyHostToDevice, c->stream));
+    launch_track_gather(d_audio, n, d_stats, shift_offset, c->seg, stride, len, c->dSegIdx, n_idx, d_mix, c->stream);
+    HIPCHK(hipGetLastError());
+    return DMX_OK;
+}
+
+extern "C" int dmx_track_overlap_add_device(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
+                                            const float *d_stats, float *d_out, int layout)
+{
+    if (!c || !d_seg_out || !d_stats || !d_out)
+        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    i64 len, stride;
+    int nseg;
+    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
+    if (rc)
+        return rc;
+    if (n_segments != nseg)
+        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: expected %d segments, got %d", nseg, n_segments);
+    launch_track_ola(d_seg_out, nseg, c->m->pm.n_sources, c->seg, stride, len, n, shift_offset, d_stats, d_out,
+                     layout == DMX_LAYOUT_EIGEN ? 1 : 0, c->stream);
+    HIPCHK(hipGetLastError());
+    return DMX_OK;
+}
+
+extern "C" int dmx_track_infer(dmx_ctx *c, const float *audio, int64_t n, int shift_offset, float *out, int layout,
+                               dmx_progress_fn progress, void *user)
+{
+    if (!c || !audio || !out || n < 2)
+        return fail(DMX_ERR_ARG, "dmx_track_infer: invalid argument");
+    if (layout != DMX_LAYOUT_EIGEN && layout != DMX_LAYOUT_PLANAR)
+        return fail(DMX_ERR_ARG, "dmx_track_infer: unknown layout %d", layout);
+    if (shift_offset < 0)
+        shift_offset = rand() % DMX_MAX_SHIFT; // model_apply.cpp:114
+    if (shift_offset >= DMX_MAX_SHIFT)
+        return fail(DMX_ERR_ARG, "dmx_track_infer: shift_offset must be < %d", DMX_MAX_SHIFT);
+    HIPCHK(hipSetDevice(c->m->device));
+    const int S = c->m->pm.n_sources;
+    const i64 seg = c->seg;
+    i64 len, stride;
+    int nseg;
+    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
+    if (rc)
+        return rc;
+    float *dAudio = nullptr, *dTmp = nullptr, *dStats = nullptr, *dMix = nullptr, *dSegOut = nullptr, *dOut = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dAudio);
+        (void)hipFree(dTmp);
+        (void)hipFree(dStats);
+        (void)hipFree(dMix);
+        (void)hipFree(dSegOut);
+        (void)hipFree(dOut);
+    };
+#define TRY(expr)                   \
+    do                              \
+    {                               \
+        int rc_ = (expr);           \
+        if (rc_)                    \
+        {                           \
+            cleanup();              \
+            return rc_;             \
+        }                           \
+    } while (0)
+#define TRYHIP(expr)                                                                            \
+    do                                                                                          \
+    {                                                                                           \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+        {                                                                                       \
+            cleanup();                                                                          \
+            return fail(DMX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
+        }                                                                                       \
+    } while (0)
+    TRYHIP(hipMalloc((void **)&dAudio, sizeof(float) * 2 * (size_t)n));
+    TRYHIP(hipMalloc((void **)&dStats, sizeof(float) * 4));
+    TRYHIP(hipMalloc((void **)&dMix, sizeof(float) * 2 * (size_t)seg * c->maxBatch));
+    TRYHIP(hipMalloc((void **)&dSegOut, sizeof(float) * (size_t)nseg * S * 2 * seg));
+    TRYHIP(hipMalloc((void **)&dOut, sizeof(float) * (size_t)S * 2 * n));
+    if (layout == DMX_LAYOUT_EIGEN)
+        TRYHIP(hipMemcpyAsync(dAudio, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    else
+    {
+        TRYHIP(hipMalloc((void **)&dTmp, sizeof(float) * 2 * (size_t)n));
+        TRYHIP(hipMemcpyAsync(dTmp, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        launch_planar_to_interleaved(dTmp, dAudio, n, c->stream);
+    }
+    if (progress)
+        progress(0.0f, "1., apply model w/ shift", user);
+    TRY(dmx_track_stats_device(c, dAudio, n, dStats));
+    std::vector<int> idx;
+    for (int g0 = 0; g0 < nseg; g0 += c->maxBatch)
+    {
+        int nb = std::min(c->maxBatch, nseg - g0);
+        idx.resize((size_t)nb);
+        for (int i = 0; i < nb; ++i)
+            idx[(size_t)i] = g0 + i;
+        TRY(dmx_track_gather_device(c, dAudio, n, dStats, shift_offset, idx.data(), nb, dMix));
+        TRY(dmx_segment_infer_device(c, dMix, dSegOut + (size_t)g0 * S * 2 * seg, nb));
+        if (progress)
+        {
+            TRYHIP(hipStreamSynchronize(c->stream));
+            char msg[128];
+            snprintf(msg, sizeof(msg), "2., apply model w/ split, segments %d..%d of %d", g0, g0 + nb - 1, nseg);
+            progress((float)(g0 + nb) / (float)nseg, msg, user);
+        }
+    }
+    TRY(dmx_track_overlap_add_device(c, dSegOut, nseg, n, shift_offset, dStats, dOut, layout));
+    TRYHIP(hipMemcpyAsync(out, dOut, sizeof(float) * (size_t)S * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    TRYHIP(hipStreamSynchronize(c->stream));
+    cleanup();
+#undef TRY
+#undef TRYHIP
+    return DMX_OK;
+}
+
+// --------------------------------------------------------------------------- debug
+extern "C" int dmx_debug_tap(dmx_ctx *c, const char *name, int64_t *shape, float *host_dst)
+{
+    if (!c || !name || !shape || c->lastBatch < 1)
+        return -1;
+    (void)hipSetDevice(c->m->device);
+    Plan *p = get_plan(c, c->lastBatch);
+    for (const Op &op : p->ops)
+        if (op.kind == OP_TAP && op.name == name)
+        {
+            int nd = 0;
+            i64 per = 1;
+            shape[nd++] = p->B;
+            for (int j = 0; j < 4 && op.tap.shape[j] > 0; ++j)
+            {
+                shape[nd++] = op.tap.shape[j];
+                per *= op.tap.shape[j];
+            }
+            if (host_dst)
+            {
+                (void)hipStreamSynchronize(c->stream);
+                for (int b = 0; b < p->B; ++b)
+                    if (hipMemcpy(host_dst + b * per, c->dA + op.tap.off + b * op.tap.batchStride, sizeof(float) * (size_t)per,
+                                  hipMemcpyDeviceToHost) != hipSuccess)
+                        return -1;
+            }
+            return nd;
+        }
+    return -1;
+}
+
+extern "C" int dmx_debug_n_ops(const dmx_ctx *c)
+{
+    if (!c)
+        return 0;
+    auto it = c->plans.find(c->maxBatch);
+    return it == c->plans.end() ? 0 : (int)it->second->ops.size();
+}
+
+// algorithmic work of one op: 2*MAC flops, and bytes with every operand read / result written once
+static void op_work(const Op &op, const char *&kernel, double &flops, double &bytes)
+{
+    static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48",
+                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64"};
+    flops = bytes = 0;
+    kernel = "?";
+    switch (op.kind)
+    {
+    case OP_IGEMM:
+    {
+        const IGemm &g = op.g;
+        const double M = (double)g.B * g.P1 * g.P0;
+        kernel = cfgNames[g.cfg];
+        flops = 2.0 * M * g.N * g.K;
+        double in = (double)g.B * g.L1 * g.L0 * g.Cin, w = (double)g.N * g.K, out = 0;
+        if (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES)
+            out = M * g.N;
+        else if (g.epi == EPI_GLU || g.epi == EPI_GN_GLU_SCALE_RES)
+            out = M * g.N / 2;
+        else if (g.epi == EPI_TRCONV)
+            out = (double)g.B * g.P1 * g.Lout * g.Cout;
+        double res = g.res >= 0 ? out : 0;
+        bytes = 4.0 * (in + w + out + res);
+        break;
+    }
+    case OP_ATTENTION:
+    {
+        const Attention &t = op.at;
+        kernel = "attention";
+        flops = 4.0 * t.B * t.H * (double)t.Tq * t.Tk * t.hs;
+        bytes = 4.0 * t.B * t.H * t.hs * (2.0 * t.Tq + 2.0 * t.Tk);
+        break;
+    }
+    case OP_STATS_REDUCE:
+        kernel = "stats_reduce";
+        bytes = 8.0 * op.sr.B * op.sr.R * op.sr.NB;
+        break;
+    case OP_STFT:
+        kernel = "stft";
+        flops = (double)op.stft.B * op.stft.T * 5.0 * 4096 * 12;
+        bytes = 4.0 * op.stft.B * ((double)op.stft.seg * 2 + (double)op.stft.T * 2048 * 4);
+        break;
+    case OP_LAYERNORM:
+        kernel = "layernorm";
+        bytes = 8.0 * op.ln.rows * op.ln.D;
+        break;
+    case OP_GN_APPLY:
+        kernel = "gn_apply";
+        bytes = 8.0 * op.gn.B * op.gn.rows * op.gn.C;
+        break;
+    case OP_ISTFT:
+        kernel = "istft";
+        flops = (double)op.istft.B * op.istft.T * op.istft.S * 5.0 * 4096 * 12;
+        bytes = 4.0 * op.istft.B * op.istft.T * op.istft.S * (2048.0 * 4 + 2 * 4096.0);
+        break;
+    case OP_OLA:
+        kernel = "ola";
+        bytes = 4.0 * op.ola.B * op.ola.S * 2 * ((double)op.ola.T * 4096 + 2.0 * op.ola.seg);
+        break;
+    default:
+        break;
+    }
+}
+
+// Times every op of the plan with HIP events on the context's stream: `reps` back-to-back
+// launches per op between one event pair. Report: one line per op
+//   name \t kernel \t ms_per_launch \t algorithmic_flops \t algorithmic_bytes
+// Leaves the arena in an undefined state (in-place ops are repeated).
+extern "C" int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, int report_cap)
+{
+    if (!c || batch < 1 || batch > c->maxBatch || reps < 1)
+        return -1;
+    (void)hipSetDevice(c->m->device);
+    Plan *p = get_plan(c, batch);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return -1;
+    int n = 0;
+    std::string all;
+    char line[512];
+    for (const Op &op : p->ops)
+    {
+        if (op.kind == OP_TAP)
+            continue;
+        launch_op(c, op, c->stream); // warm
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; ++r)
+            launch_op(c, op, c->stream);
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        const char *kernel;
+        double fl, by;
+        op_work(op, kernel, fl, by);
+        snprintf(line, sizeof(line), "%s\t%s\t%.6f\t%.6e\t%.6e\n", op.name.c_str(), kernel, t / reps, fl, by);
+        all += line;
+        ++n;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (report && report_cap > 0)
+    {
+        size_t k = std::min((size_t)report_cap - 1, all.size());
+        std::memcpy(report, all.data(), k);
+        report[k] = 0;
+    }
+    return n;
+}

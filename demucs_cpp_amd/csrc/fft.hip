@@ -1,0 +1,225 @@
+// fft.hip — STFT / ISTFT kernels for gfx950.
+//
+// Restates /root/reference/src/dsp.cpp:51-185 (stft/istft, nfft 4096, hop 1024,
+// periodic Hann, 1/sqrt(N) scaling, unscaled inverse) fused with the surrounding glue
+// of src/model_inference.cpp: symmetric padding :22-46 (Q2), frame slice [2, 2+le)
+// :75-78, CaC packing :88-99 and its statistics :115-118 on the way in; de-normalise
+// :380-393, CaC undo + zero Nyquist :409-444 on the way out.
+//
+// Both stereo channels of a frame share ONE 4096-point complex FFT (z = x_L + i x_R;
+// the two half spectra are separated with the conjugate-symmetry identity), done as a
+// 12-stage radix-2 Stockham autosort FFT in LDS by one 256-thread workgroup per frame.
+// The whole STFT/ISTFT is < 1% of the segment's HBM bytes; the design goal here is
+// coalesced float2/float4 global access, not FFT throughput.
+#include "kernels.h"
+
+namespace dmx
+{
+
+#define FFT_N 4096
+#define FFT_LOG 12
+
+// In-LDS Stockham radix-2 DIF FFT of FFT_N complex points. After the call the result is
+// in `a` (12 stages = even). sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse.
+// tw[k] = exp(-2 pi i k / 4096), k < 2048.
+template <int SIGN>
+__device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__restrict__ tw, int tid)
+{
+    float2 *x = a, *y = b;
+#pragma unroll 1
+    for (int st = 0; st < FFT_LOG; ++st)
+    {
+        const int s = 1 << st;          // stride
+        const int m = (FFT_N >> st) >> 1; // half length of the sub-transform
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const int j = tid + i * 256; // butterfly index 0..2047
+            const int p = j >> st, q = j & (s - 1);
+            const float2 u = x[q + s * p];
+            const float2 v = x[q + s * (p + m)];
+            float2 w = tw[p << st];
+            if (SIGN > 0)
+                w.y = -w.y;
+            const float2 d = make_float2(u.x - v.x, u.y - v.y);
+            y[q + s * (2 * p)] = make_float2(u.x + v.x, u.y + v.y);
+            y[q + s * (2 * p + 1)] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+        }
+        __syncthreads();
+        float2 *t = x;
+        x = y;
+        y = t;
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red, int tid)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0)
+        red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
+{
+    __shared__ float2 bufA[FFT_N];
+    __shared__ float2 bufB[FFT_N];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float2 *tw = reinterpret_cast<const float2 *>(p.twiddle);
+    const float2 *mix = reinterpret_cast<const float2 *>(p.mix) + (i64)b * p.seg;
+
+    // windowed frame, both channels packed as one complex signal (re = L, im = R)
+    for (int i = tid; i < FFT_N; i += 256)
+    {
+        i64 j = (i64)t * 1024 + i - p.pad;
+        if (j < 0)
+            j = -1 - j; // symmetric (edge-duplicating) reflection, Q2
+        if (j >= p.seg)
+            j = 2 * (i64)p.seg - 1 - j;
+        const float2 v = mix[j];
+        const float w = p.window[i];
+        bufA[i] = make_float2(v.x * w, v.y * w);
+    }
+    // raw-mix statistics of this hop (time-branch z-norm, model_inference.cpp:138-141)
+    double sT = 0.0, qT = 0.0;
+    for (int i = tid; i < 1024; i += 256)
+    {
+        i64 j = (i64)t * 1024 + i;
+        if (j < p.seg)
+        {
+            const float2 v = mix[j];
+            sT += (double)v.x + (double)v.y;
+            qT += (double)v.x * v.x + (double)v.y * v.y;
+        }
+    }
+    __syncthreads();
+    fft4096<-1>(bufA, bufB, tw, tid);
+
+    // split the two real spectra, scale by 1/sqrt(N), write CaC (re0, im0, re1, im1)
+    float4 *out = reinterpret_cast<float4 *>(p.x) + ((i64)b * p.T + t) * 2048;
+    double sF = 0.0, qF = 0.0;
+    const float sc = 1.0f / 64.0f;
+    for (int k = tid; k < 2048; k += 256)
+    {
+        const float2 zk = bufA[k];
+        const float2 zn = bufA[(FFT_N - k) & (FFT_N - 1)];
+        // X0 = (Z[k] + conj(Z[N-k]))/2 ; X1 = -i (Z[k] - conj(Z[N-k]))/2
+        const float re0 = 0.5f * (zk.x + zn.x) * sc, im0 = 0.5f * (zk.y - zn.y) * sc;
+        const float re1 = 0.5f * (zk.y + zn.y) * sc, im1 = -0.5f * (zk.x - zn.x) * sc;
+        out[k] = make_float4(re0, im0, re1, im1);
+        sF += (double)re0 + (double)im0 + (double)re1 + (double)im1;
+        qF += (double)re0 * re0 + (double)im0 * im0 + (double)re1 * re1 + (double)im1 * im1;
+    }
+    sF = block_sum(sF, red, tid);
+    qF = block_sum(qF, red, tid);
+    sT = block_sum(sT, red, tid);
+    qT = block_sum(qT, red, tid);
+    if (tid == 0)
+    {
+        float *rs = p.rowstat + ((i64)b * p.T + t) * 2;
+        rs[0] = (float)sF;
+        rs[1] = (float)qF;
+        float *rt = p.rowstatT + ((i64)b * p.T + t) * 2;
+        rt[0] = (float)sT;
+        rt[1] = (float)qT;
+    }
+}
+
+void launch_stft(const StftArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(stft_kernel, dim3(a.T, a.B), dim3(256), 0, s, a);
+}
+
+// One workgroup per (frame t, source s, batch b): inverse transform of both channels.
+__global__ __launch_bounds__(256) void istft_kernel(const IstftArgs p)
+{
+    __shared__ float2 bufA[FFT_N];
+    __shared__ float2 bufB[FFT_N];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x, src = blockIdx.y, b = blockIdx.z;
+    const float2 *tw = reinterpret_cast<const float2 *>(p.twiddle);
+    const int CS = 4 * p.S;
+    const float mean = p.stats[b * 4], stdv = p.stats[b * 4 + 2];
+    const float *xin = p.x + (((i64)b * p.T + t) * 2048) * CS + src * 4;
+
+    // Z[k] = X0[k] + i X1[k] with Hermitian extension; X*sqrt(N) (dsp.cpp:160-165);
+    // DC imaginary parts ignored, Nyquist bin = 0 (model_inference.cpp:439-442)
+    for (int k = tid; k < 2048; k += 256)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(xin + (i64)k * CS);
+        float re0 = (stdv * v.x + mean) * 64.0f, im0 = (stdv * v.y + mean) * 64.0f;
+        float re1 = (stdv * v.z + mean) * 64.0f, im1 = (stdv * v.w + mean) * 64.0f;
+        if (k == 0)
+        {
+            im0 = 0.f;
+            im1 = 0.f;
+        }
+        // X0 + i X1 = (re0 - im1) + i (im0 + re1)
+        bufA[k] = make_float2(re0 - im1, im0 + re1);
+        if (k > 0) // conj(X0) + i conj(X1) = (re0 + im1) + i (re1 - im0)
+            bufA[FFT_N - k] = make_float2(re0 + im1, re1 - im0);
+    }
+    if (tid == 0)
+        bufA[2048] = make_float2(0.f, 0.f);
+    __syncthreads();
+    fft4096<+1>(bufA, bufB, tw, tid);
+    float *f0 = p.frames + ((((i64)b * p.S + src) * 2 + 0) * p.T + t) * 4096;
+    float *f1 = p.frames + ((((i64)b * p.S + src) * 2 + 1) * p.T + t) * 4096;
+    for (int i = tid; i < FFT_N; i += 256)
+    {
+        const float2 z = bufA[i];
+        const float w = p.window[i];
+        f0[i] = z.x * w;
+        f1[i] = z.y * w;
+    }
+}
+
+void launch_istft(const IstftArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(istft_kernel, dim3(a.T, a.S, a.B), dim3(256), 0, s, a);
+}
+
+// Overlap-add of the windowed inverse frames with window-sum-square normalisation
+// (dsp.cpp:174-183), crop (dsp.cpp:113-116, model_inference.cpp:454-455) and sum with the
+// de-normalised time branch (model_inference.cpp:396-405,460).
+__global__ __launch_bounds__(256) void ola_kernel(const OlaArgs p)
+{
+    const int plane = blockIdx.y; // (b*S + src)*2 + ch
+    const int ch = plane & 1, src = (plane >> 1) % p.S, b = (plane >> 1) / p.S;
+    const float meanT = p.statsT[b * 4], stdT = p.statsT[b * 4 + 2];
+    const float *fr = p.frames + (i64)plane * p.T * 4096;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.seg; i += gridDim.x * 256)
+    {
+        const int n = 2048 + p.pad + i;
+        const int f1 = n >> 10;
+        float acc = 0.f;
+#pragma unroll
+        for (int f = f1 - 3; f <= f1; ++f)
+        {
+            const int t = f - 2;
+            if (t >= 0 && t < p.T)
+            {
+                const float yv = fr[(i64)t * 4096 + (n - f * 1024)];
+                acc += yv * 1.0f / 4096.0f / (p.wss[n] + 1e-8f);
+            }
+        }
+        const float tb = stdT * p.xt[((i64)b * p.seg + i) * (2 * p.S) + src * 2 + ch] + meanT;
+        p.out[(i64)plane * p.seg + i] = acc + tb;
+    }
+}
+
+void launch_ola(const OlaArgs &a, hipStream_t s)
+{
+    int gx = (a.seg + 255) / 256;
+    if (gx > 1024)
+        gx = 1024;
+    hipLaunchKernelGGL(ola_kernel, dim3(gx, a.B * a.S * 2), dim3(256), 0, s, a);
+}
+
+} // namespace dmx

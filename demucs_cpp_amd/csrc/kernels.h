@@ -1,0 +1,120 @@
+// kernels.h — launch interface of the hand-written gfx950 kernels (device pointers resolved).
+// Semantics of every op are specified by plan.h and, executable, by tests/cpu_interp.cpp.
+#pragma once
+#include "plan.h"
+#include <hip/hip_runtime.h>
+
+namespace dmx
+{
+
+struct GemmArgs
+{
+    const float *X;
+    i64 xBS;
+    int B, P1, P0, L1, L0, Cin;
+    int S1, stride1, dil1, pad1, seg0, stride0, pad0, K, Kp;
+    int pro;
+    const float *proStats, *proW, *proB;
+    int G0;
+    const float *Wt, *bias;
+    int N, Np;
+    int epi, act;
+    float *Y;
+    i64 yBS;
+    int ldy;
+    const float *res, *scale, *epiStats, *epiW, *epiB;
+    float *rowstat;
+    int NB;
+    const float *table;
+    float tableScale;
+    int Lout, Cout;
+    i64 M;
+};
+
+void launch_igemm(int cfg, const GemmArgs &a, hipStream_t s);
+
+struct ReduceArgs
+{
+    const float *rowstat;
+    float *out;
+    int B, R, NB, G0;
+    double count;
+    int mode;
+    float eps;
+};
+void launch_stats_reduce(const ReduceArgs &a, hipStream_t s);
+
+struct StftArgs
+{
+    const float *mix;
+    float *x, *rowstat, *rowstatT;
+    int B, T, seg, pad;
+    const float *window, *twiddle;
+};
+void launch_stft(const StftArgs &a, hipStream_t s);
+
+struct LnArgs
+{
+    const float *x;
+    float *y;
+    int rows, D, rowsPerBatch;
+    const float *w, *b, *pe;
+    float eps;
+};
+void launch_layernorm(const LnArgs &a, hipStream_t s);
+
+struct GnArgs
+{
+    const float *x;
+    float *y;
+    const float *res;
+    int B, rows, C;
+    const float *stats, *w, *b;
+};
+void launch_gn_apply(const GnArgs &a, hipStream_t s);
+
+struct AttnArgs
+{
+    const float *q, *k, *v;
+    float *o;
+    int ldq, ldk, ldv, ldo;
+    i64 qB, kB, vB, oB;
+    int B, Tq, Tk, H, hs;
+    float scale;
+};
+void launch_attention(const AttnArgs &a, hipStream_t s);
+
+struct IstftArgs
+{
+    const float *x, *stats;
+    float *frames;
+    int B, T, S;
+    const float *window, *twiddle;
+};
+void launch_istft(const IstftArgs &a, hipStream_t s);
+
+struct OlaArgs
+{
+    const float *frames, *xt, *statsT, *wss;
+    float *out;
+    int B, T, S, seg, pad;
+};
+void launch_ola(const OlaArgs &a, hipStream_t s);
+
+// ---- track level (model_apply.cpp:60-288) ----
+// partial (sum, sumsq) of the mono reference (mean over channels); audio interleaved [n][2]
+void launch_track_stats(const float *audio, i64 n, double *partials, int nblk, hipStream_t s);
+// stats[0]=mean, stats[1]=std (unbiased) from partials
+void launch_track_stats_final(const double *partials, int nblk, i64 n, float *stats, hipStream_t s);
+// chunk extraction: mixes[i] = segment `segIdx[i]` of the normalised, shifted, zero-padded track,
+// centred in a zero segment (segment_inference, model_apply.cpp:250-288)
+void launch_track_gather(const float *audio, i64 n, const float *stats, int shiftOffset, i64 seg, i64 stride,
+                         i64 len, const int *segIdx, int nIdx, float *mixes, hipStream_t s);
+// overlap-add of nSeg segment outputs [nSeg][S][2][seg] (segment ids 0..nSeg-1) into out.
+// layout 0: planar [S][2][n]; layout 1: Eigen column-major image (s + S*(c + 2*i))
+void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len, i64 n, int shiftOffset,
+                      const float *stats, float *out, int layout, hipStream_t s);
+// interleaved <-> planar helpers
+void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream_t s);
+
+} // namespace dmx

@@ -1,0 +1,131 @@
+/* demucs_hip.h — C ABI of the MI355X-native HTDemucs inference path.
+ *
+ * This is the drop-in boundary for the hot path of sevagh/demucs.cpp (reference at
+ * /root/reference, citations below are file:line in that tree). The reference has no
+ * FFI/plugin registry: its boundary is the C++ API in namespace demucscpp
+ * (src/model.hpp:649-666). Each entry point here replaces one of those functions; the
+ * header-only C++ shim demucs_cpp_amd/host/demucscpp_hip.hpp restates the reference
+ * signatures on top of this ABI, and INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions: plain C, opaque handles, int status (0 = DMX_OK), no exceptions or C++
+ * types across the ABI, dmx_last_error() gives the message of the last failure on the
+ * calling thread. All audio is fp32, 44.1 kHz, stereo. A context is NOT thread-safe;
+ * create one context per host thread / stream (the model handle is immutable after load
+ * and may be shared, like the reference's `const demucs_model&`).
+ *
+ * There is NO CPU fallback: every entry point that computes fails with
+ * DMX_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DEMUCS_HIP_H
+#define DEMUCS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define DMX_OK 0
+#define DMX_ERR_IO 1          /* weight file cannot be opened / truncated            */
+#define DMX_ERR_FORMAT 2      /* bad magic, unknown tensor, wrong element count       */
+#define DMX_ERR_NO_DEVICE 3   /* no usable HIP device (there is no CPU fallback)      */
+#define DMX_ERR_HIP 4         /* HIP runtime error                                    */
+#define DMX_ERR_ARG 5         /* invalid argument                                     */
+
+#define DMX_SEGMENT_SAMPLES 343980 /* 7.8 s @ 44.1 kHz, src/model.hpp:652, :20        */
+#define DMX_MAX_SHIFT 22050        /* 0.5 s, src/model.hpp:654                         */
+
+/* Audio memory layouts at the boundary.
+ * DMX_LAYOUT_EIGEN : the exact memory image of the reference's Eigen types
+ *     input  Eigen::MatrixXf(2, N)  column-major  = interleaved stereo L0 R0 L1 R1 ...
+ *     output Eigen::Tensor3dXf(S, 2, N) column-major: element (s,c,n) at s + S*(c + 2n)
+ *     (src/model_apply.cpp:60-62; cli-apps/demucs.cpp:21-76,185-204)
+ * DMX_LAYOUT_PLANAR: input [2][N], output [S][2][N] row-major (cf. the wasm glue's
+ *     per-stem planar pointers, src_wasm/demucs.cpp:82-93). */
+#define DMX_LAYOUT_EIGEN 0
+#define DMX_LAYOUT_PLANAR 1
+
+    typedef struct dmx_model dmx_model;
+    typedef struct dmx_ctx dmx_ctx;
+
+    /* progress callback, same meaning as demucscpp::ProgressCallback (src/model.hpp:17):
+     * fraction in [0,1] and a message; invoked synchronously on the calling thread. */
+    typedef void (*dmx_progress_fn)(float progress, const char *message, void *user);
+
+    const char *dmx_last_error(void);
+    int dmx_device_count(void);
+
+    /* Replaces demucscpp::load_demucs_model (src/model.hpp:649-650, src/model_load.cpp:50):
+     * reads a dmc4/dmc6 ggml-style fp16 weight file, repacks it and uploads it to
+     * `device`. Same failure cases as the reference (open failure, bad magic, unknown
+     * tensor name, element-count mismatch) plus "tensor missing". */
+    int dmx_model_load(const char *model_file, int device, dmx_model **out);
+    void dmx_model_free(dmx_model *m);
+    int dmx_model_n_sources(const dmx_model *m); /* 4 or 6 (demucs_model::is_4sources) */
+    int dmx_model_n_tensors(const dmx_model *m);
+    int dmx_model_device(const dmx_model *m);
+
+    /* Execution context = the reference's demucs_segment_buffers + stft_buffers
+     * (src/model.hpp:569-647, src/dsp.hpp:20-101) for `max_batch` segments in flight,
+     * allocated once in HBM. segment_samples = 0 selects DMX_SEGMENT_SAMPLES. */
+    int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out);
+    void dmx_ctx_free(dmx_ctx *c);
+    int64_t dmx_ctx_segment_samples(const dmx_ctx *c);
+    int dmx_ctx_max_batch(const dmx_ctx *c);
+    int64_t dmx_ctx_arena_bytes(const dmx_ctx *c);
+    int dmx_ctx_synchronize(dmx_ctx *c);
+
+    /* Replaces demucscpp::model_inference (src/model.hpp:662-666,
+     * src/model_inference.cpp:48): one full segment, host pointers.
+     *   mix : 2 x segment_samples in `layout`; out : S x 2 x segment_samples in `layout`. */
+    int dmx_segment_infer(dmx_ctx *c, const float *mix, float *out, int layout);
+
+    /* Same on device memory, `batch` (<= max_batch) segments, asynchronous on the
+     * context's stream (pair with dmx_ctx_synchronize):
+     *   d_mix : [batch][segment_samples][2] interleaved, d_out : [batch][S][2][segment_samples] planar. */
+    int dmx_segment_infer_device(dmx_ctx *c, const float *d_mix, float *d_out, int batch);
+
+    /* Replaces demucscpp::demucs_inference (src/model.hpp:658-660,
+     * src/model_apply.cpp:60-288): normalise, shift, overlapping-segment loop,
+     * overlap-add, trim, de-normalise. shift_offset in [0, DMX_MAX_SHIFT) replaces the
+     * reference's unseeded rand() % 22050 (src/model_apply.cpp:114); pass -1 to draw
+     * rand() % 22050 like the reference.  audio : 2 x n, out : S x 2 x n, both `layout`. */
+    int dmx_track_infer(dmx_ctx *c, const float *audio, int64_t n, int shift_offset, float *out, int layout,
+                        dmx_progress_fn progress, void *user);
+
+    /* ---- building blocks of dmx_track_infer on device memory (segment sharding over
+     * several GPUs: one process per GPU runs steps 2-3 on its share, results are gathered
+     * (RCCL) to the root which runs step 4). All asynchronous on the context's stream.   */
+    /* 0. geometry of the segment loop (src/model_apply.cpp:145-189) */
+    int dmx_track_geometry(const dmx_ctx *c, int64_t n, int shift_offset, int64_t *shifted_len, int *n_segments,
+                           int64_t *stride);
+    /* 1. mean / unbiased std of the mono reference (src/model_apply.cpp:72-78);
+     *    d_audio interleaved [n][2]; d_stats: 2 floats */
+    int dmx_track_stats_device(dmx_ctx *c, const float *d_audio, int64_t n, float *d_stats);
+    /* 2. chunks seg_idx[0..n_idx) of the normalised, shifted, zero-padded track, each
+     *    centred in a zero segment (src/model_apply.cpp:93-138,189-194,250-262)
+     *    -> d_mix [n_idx][segment_samples][2]; seg_idx is a HOST array */
+    int dmx_track_gather_device(dmx_ctx *c, const float *d_audio, int64_t n, const float *d_stats, int shift_offset,
+                                const int *seg_idx, int n_idx, float *d_mix);
+    /* 3. dmx_segment_infer_device on d_mix                                               */
+    /* 4. triangle-weighted overlap-add of ALL n_segments outputs (segment order), divide
+     *    by the weight sum, trim, de-normalise (src/model_apply.cpp:171-246,129-135,88);
+     *    d_seg_out [n_segments][S][2][segment_samples]; d_out S x 2 x n in `layout`     */
+    int dmx_track_overlap_add_device(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
+                                     const float *d_stats, float *d_out, int layout);
+
+    /* ---- debug taps (layer-level parity tests, cf. the reference's print-only layer tests
+     * test/test_layers.cpp:1390-2157): copies a named intermediate activation of the last
+     * dmx_segment_infer* call to the host. shape[0] is the batch. Returns ndim or -1.      */
+    int dmx_debug_tap(dmx_ctx *c, const char *name, int64_t *shape, float *host_dst);
+    int dmx_debug_n_ops(const dmx_ctx *c);
+    /* per-op timing with HIP events on the context's stream (`reps` launches per op); fills
+     * `report` with lines "name\tkernel\tms_per_launch\talgorithmic_flops\talgorithmic_bytes".
+     * Returns the number of ops or -1. Leaves the activations undefined.                   */
+    int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, int report_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMUCS_HIP_H */
