@@ -44,6 +44,15 @@ class DmxError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; a process must hold ONE HIP runtime.
+        # Importing torch first makes the dynamic linker bind our NEEDED libamdhip64.so.7 to the
+        # copy torch already loaded (same SONAME), so torch tensors / RCCL and this library share
+        # the device context. (Loading ours first left torch with "No HIP GPUs are available".)
+        if os.environ.get("DMX_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # torch is plumbing only; the library works without it
+                pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `make` or __graft_entry__.build() (no fallback exists)")
         L = ctypes.CDLL(LIB_PATH)

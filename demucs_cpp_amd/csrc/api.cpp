@@ -210,7 +210,9 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s)
     case OP_STATS_REDUCE:
     {
         const StatsReduce &r = op.sr;
-        launch_stats_reduce(ReduceArgs{a(r.rowstat), a(r.out), r.B, r.R, r.NB, r.G0, r.count, r.mode, r.eps}, s);
+        launch_stats_reduce(ReduceArgs{a(r.rowstat), a(r.out), r.B, r.R, r.NB, r.G0, r.count, r.mode, r.eps,
+                                       reinterpret_cast<double *>(a(r.scratch)), r.nchunk},
+                            s);
         break;
     }
     case OP_STFT:

@@ -41,6 +41,8 @@ struct ReduceArgs
     double count;
     int mode;
     float eps;
+    double *scratch;
+    int nchunk;
 };
 void launch_stats_reduce(const ReduceArgs &a, hipStream_t s);
 

@@ -63,6 +63,66 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const ReduceArgs p)
     }
 }
 
+// G0 <= 1 (one group per batch element, up to 86k rows): two stages.
+// stage 1: grid (nchunk, B); each workgroup sums a contiguous chunk of the [R*NB] float2 entries
+__global__ __launch_bounds__(256) void stats_partial_kernel(const ReduceArgs p)
+{
+    __shared__ double red[4][2];
+    const int b = blockIdx.y;
+    const i64 entries = (i64)p.R * p.NB;
+    const i64 per = (entries + p.nchunk - 1) / p.nchunk;
+    const i64 lo = (i64)blockIdx.x * per, hi = lo + per < entries ? lo + per : entries;
+    const float2 *src = reinterpret_cast<const float2 *>(p.rowstat) + (i64)b * entries;
+    double s = 0.0, q = 0.0;
+    for (i64 i = lo + threadIdx.x; i < hi; i += 256)
+    {
+        const float2 v = src[i];
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        red[threadIdx.x >> 6][0] = s;
+        red[threadIdx.x >> 6][1] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double *dst = p.scratch + ((i64)b * p.nchunk + blockIdx.x) * 2;
+        dst[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        dst[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+}
+// stage 2: one wave per batch element sums the nchunk partials in index order
+__global__ __launch_bounds__(64) void stats_final_kernel(const ReduceArgs p)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0)
+        return;
+    double S = 0.0, Q = 0.0;
+    for (int i = 0; i < p.nchunk; ++i)
+    {
+        S += p.scratch[((i64)b * p.nchunk + i) * 2];
+        Q += p.scratch[((i64)b * p.nchunk + i) * 2 + 1];
+    }
+    const double mean = S / p.count;
+    double var = (Q - p.count * mean * mean) / (p.count - 1.0);
+    if (var < 0.0)
+        var = 0.0;
+    float4 o;
+    o.x = (float)mean;
+    o.z = (float)sqrt(var);
+    o.y = p.mode == MODE_RSTD ? (float)(1.0 / sqrt(var + (double)p.eps)) : (float)(1.0 / (sqrt(var) + (double)p.eps));
+    o.w = 0.f;
+    reinterpret_cast<float4 *>(p.out)[b] = o;
+}
+
 void launch_stats_reduce(const ReduceArgs &a, hipStream_t s)
 {
     const int G = a.G0 > 1 ? a.G0 : 1;
@@ -71,7 +131,10 @@ void launch_stats_reduce(const ReduceArgs &a, hipStream_t s)
     else if (G > 1)
         hipLaunchKernelGGL(stats_reduce_kernel<8>, dim3((G + 7) / 8, a.B), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(stats_reduce_kernel<1>, dim3(1, a.B), dim3(256), 0, s, a);
+    {
+        hipLaunchKernelGGL(stats_partial_kernel, dim3(a.nchunk, a.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(stats_final_kernel, dim3(a.B), dim3(64), 0, s, a);
+    }
 }
 
 // --------------------------------------------------------------------------- LayerNorm

@@ -7,6 +7,7 @@
 // reference are documented per op in DESIGN.md §4.
 #include "plan.h"
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
@@ -65,6 +66,7 @@ struct Builder
     const PackedModel &pm;
     Plan &pl;
     i64 top = 0;
+    i64 redScratch[2] = {-1, -1};
     Builder(const PackedModel &m, Plan &p) : pm(m), pl(p) {}
 
     i64 alloc(i64 n)
@@ -117,7 +119,15 @@ struct Builder
         op.kind = OP_STATS_REDUCE;
         op.stream = stream;
         op.name = name;
-        op.sr = StatsReduce{rowstat, out, B, R, NB, G0, count, mode, 1e-5f};
+        op.sr = StatsReduce{rowstat, out, B, R, NB, G0, count, mode, 1e-5f, -1, 0};
+        if (G0 <= 1)
+        {
+            // two-stage: nchunk workgroups per batch element, then one finalising workgroup
+            i64 entries = (i64)R * NB;
+            int nchunk = (int)std::min<i64>(256, (entries + 2047) / 2048);
+            op.sr.nchunk = std::max(nchunk, 1);
+            op.sr.scratch = stream == 0 ? redScratch[0] : redScratch[1];
+        }
         pl.ops.push_back(op);
     }
     void push_tap(const std::string &name, i64 off, std::initializer_list<int> shape, i64 batchStride)
@@ -278,6 +288,8 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
     const i64 aXcac = b.alloc((i64)B * T * 2048 * 4);
     const i64 aRsX = b.alloc((i64)B * T * 2), aRsT = b.alloc((i64)B * T * 2);
     const i64 aStF = b.alloc((i64)B * 4), aStT = b.alloc((i64)B * 4);
+    b.redScratch[0] = b.alloc((i64)B * 256 * 4);
+    b.redScratch[1] = b.alloc((i64)B * 256 * 4);
     i64 aY[4], aX[4], aYt[4], aXt[4]; // conv outputs (dconv in place), saved skips
     for (int i = 0; i < 4; ++i)
     {

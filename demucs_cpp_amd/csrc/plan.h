@@ -112,6 +112,8 @@ struct StatsReduce
     double count; // elements per group
     int mode;
     float eps;
+    i64 scratch; // A: [B][nchunk][4] (two doubles) partials for the G0 <= 1 two-stage reduction, or -1
+    int nchunk;
 };
 
 struct Stft

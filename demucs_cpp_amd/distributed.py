@@ -1,0 +1,92 @@
+"""Segment-sharded track inference over the GPUs of one node (one process per GPU).
+
+The overlapping-segment loop of the reference (src/model_apply.cpp:189-235, /root/reference)
+is embarrassingly parallel: every iteration reads a slice of the shifted track and produces an
+independent (S, 2, segment) block; the only coupling is the weighted overlap-add. So:
+
+  * every rank holds the weights and the (small) input track;
+  * segment g is owned by rank g % world (all segments cost the same: short tails are
+    zero-padded to a full segment, Q8);
+  * each rank runs its segments through the hot path in batches;
+  * ONE exchange step: the per-segment outputs are gathered to the root (RCCL gather over xGMI;
+    11 MB per 4-source segment), equal-sized slabs padded to ceil(n_seg/world) segments;
+  * the root overlap-adds ALL segments in segment order (bit-identical to the 1-GPU result
+    because every output sample accumulates its <= 2 covering segments in increasing index).
+
+`backend` abstracts the three device operations so the bookkeeping can be tested on CPU with
+the gloo backend (tests/test_distributed_cpu.py); the product backend is HipBackend.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+
+def owned_segments(n_segments: int, rank: int, world: int) -> List[int]:
+    return list(range(rank, n_segments, world))
+
+
+def slab_size(n_segments: int, world: int) -> int:
+    return (n_segments + world - 1) // world
+
+
+class HipBackend:
+    """Device ops through the C ABI (include/demucs_hip.h) on torch-owned HBM tensors."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.S = ctx.S
+        self.seg = ctx.seg
+        self.max_batch = ctx.max_batch
+        self.device = torch.device("cuda", ctx.model.device)
+
+    def geometry(self, n, shift):
+        return self.ctx.track_geometry(n, shift)  # (shifted_len, n_segments, stride)
+
+    def stats(self, audio_il: torch.Tensor) -> torch.Tensor:
+        st = torch.zeros(4, device=self.device)
+        self.ctx.track_stats_device(audio_il.data_ptr(), audio_il.shape[0], st.data_ptr())
+        return st
+
+    def infer_segments(self, audio_il, stats, shift, seg_ids: List[int], out: torch.Tensor):
+        """out[i] = hot path of segment seg_ids[i]; out: [len(seg_ids)][S][2][seg] on device."""
+        n = audio_il.shape[0]
+        mix = torch.empty((self.max_batch, self.seg, 2), device=self.device)
+        for i0 in range(0, len(seg_ids), self.max_batch):
+            ids = seg_ids[i0:i0 + self.max_batch]
+            self.ctx.track_gather_device(audio_il.data_ptr(), n, stats.data_ptr(), shift, ids, mix.data_ptr())
+            self.ctx.segment_device(mix.data_ptr(), out[i0].data_ptr(), len(ids))
+        self.ctx.synchronize()
+
+    def overlap_add(self, seg_out: torch.Tensor, n_segments, n, shift, stats) -> torch.Tensor:
+        out = torch.empty((self.S, 2, n), device=self.device)
+        self.ctx.track_overlap_add_device(seg_out.data_ptr(), n_segments, n, shift, stats.data_ptr(), out.data_ptr())
+        self.ctx.synchronize()
+        return out
+
+
+def track_infer_sharded(backend, audio_il: torch.Tensor, shift: int, dist=None, rank: int = 0, world: int = 1,
+                        root: int = 0) -> Optional[torch.Tensor]:
+    """audio_il: [n][2] interleaved stereo on the backend's device (same on every rank).
+    Returns (S, 2, n) on the root, None elsewhere."""
+    n = int(audio_il.shape[0])
+    _, n_seg, _ = backend.geometry(n, shift)
+    S, seg = backend.S, backend.seg
+    stats = backend.stats(audio_il)  # every rank computes the same statistics locally
+    mine = owned_segments(n_seg, rank, world)
+    slab = slab_size(n_seg, world)
+    local = torch.zeros((slab, S, 2, seg), device=audio_il.device, dtype=torch.float32)
+    if mine:
+        backend.infer_segments(audio_il, stats, shift, mine, local)
+    if world > 1:
+        gathered = [torch.empty_like(local) for _ in range(world)] if rank == root else None
+        dist.gather(local, gathered, dst=root)
+        if rank != root:
+            return None
+        # slab r, slot j holds segment r + j*world  ->  restore segment order
+        stacked = torch.stack(gathered, dim=1)  # [slab][world][S][2][seg]
+        all_seg = stacked.reshape(slab * world, S, 2, seg)[:n_seg].contiguous()
+    else:
+        all_seg = local[:n_seg]
+    return backend.overlap_add(all_seg, n_seg, n, shift, stats)

@@ -1,0 +1,105 @@
+"""C-ABI surface checks that need no GPU: the library loads, exports every symbol the
+header declares, and fails loudly (no CPU fallback) - loader error behaviour mirrors
+/root/reference/src/model_load.cpp:64-69,97-102,1065-1070,1096-1105."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dmx():
+    so = os.path.join(ROOT, "demucs_cpp_amd", "lib", "libdemucs_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ROOT, "demucs_cpp_amd/lib/libdemucs_hip.so"], stdout=subprocess.DEVNULL)
+    from demucs_cpp_amd import binding
+    return binding
+
+
+def test_header_and_library_export_the_same_symbols(dmx):
+    hdr = open(os.path.join(ROOT, "include", "demucs_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(dmx_[a-z_0-9]+)\s*\(", hdr)) - {"dmx_progress_fn"})
+    assert declared == sorted(dmx.EXPORTS)
+    L = dmx.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_no_torch_types_in_the_abi():
+    hdr = open(os.path.join(ROOT, "include", "demucs_hip.h")).read()
+    assert "torch" not in hdr.lower() and "std::" not in hdr and "Eigen::" not in hdr.replace("Eigen::MatrixXf", "").replace("Eigen::Tensor3dXf", "")
+
+
+def test_load_missing_file_fails(dmx):
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model("/nonexistent/model.bin")
+    assert e.value.code == 1 and "failed to open" in str(e.value)
+
+
+def test_load_bad_magic_fails(dmx, tmp_path):
+    p = tmp_path / "bad.bin"
+    p.write_bytes(struct.pack("<I", 0x646D6333) + b"\0" * 64)  # "dmc3" (v3) is out of scope
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(p))
+    assert e.value.code == 2 and "bad magic" in str(e.value)
+
+
+def _write(path, ns, tensors):
+    from demucs_cpp_amd.weights import write_model
+    write_model(str(path), tensors, ns)
+
+
+def test_load_unknown_tensor_and_wrong_size_fail(dmx, tmp_path):
+    from demucs_cpp_amd.weights import synth_weights
+    w = synth_weights(4, 0)
+    bad = dict(w)
+    bad["encoder.0.conv.bogus"] = np.zeros(3, np.float16)
+    _write(tmp_path / "unk.bin", 4, bad)
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "unk.bin"))
+    assert e.value.code == 2 and "failed to load encoder.0.conv.bogus" in str(e.value)
+    bad = dict(w)
+    bad["encoder.0.conv.bias"] = np.zeros(47, np.float16)
+    _write(tmp_path / "size.bin", 4, bad)
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "size.bin"))
+    assert e.value.code == 2 and "wrong size" in str(e.value)
+    bad = dict(w)
+    del bad["freq_emb.embedding.weight"]
+    _write(tmp_path / "missing.bin", 4, bad)
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "missing.bin"))
+    assert e.value.code == 2 and "missing" in str(e.value)
+
+
+def test_six_source_file_with_four_source_tensor_shapes_fails(dmx, tmp_path):
+    from demucs_cpp_amd.weights import synth_weights
+    w = synth_weights(4, 0)  # 4s shapes written under the dmc6 magic: resamplers are unknown there
+    _write(tmp_path / "mix.bin", 6, w)
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "mix.bin"))
+    assert e.value.code == 2
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this check is for GPU-less hosts")
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback(dmx, tmp_models):
+    assert dmx.device_count() == 0
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(tmp_models[4])
+    assert e.value.code == 3 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    # the oracle is test infrastructure: nothing under the product tree may mention it
+    for base in ("demucs_cpp_amd", "include", "cli"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "oracle_lib" not in txt and "liboracle" not in txt and "cpu_interp" not in txt.replace("tests/cpu_interp.cpp", ""), os.path.join(dp, f)

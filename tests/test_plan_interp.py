@@ -1,0 +1,65 @@
+"""Validates the product's host-side plan (demucs_cpp_amd/csrc/plan.cpp: op list and
+descriptors) and weight repacking (model_pack.cpp) on the CPU by interpreting the plan with
+tests/cpu_interp.cpp (the executable specification of every HIP kernel) and comparing with the
+fp64 golden vectors and the oracle. No GPU needed; the HIP kernels are checked against the same
+oracle in test_gpu_parity.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "_build", "libcpu_interp.so")
+
+
+@pytest.fixture(scope="module")
+def interp():
+    srcs = [os.path.join(ROOT, "tests", "cpu_interp.cpp")] + [os.path.join(ROOT, "demucs_cpp_amd", "csrc", f) for f in ("plan.cpp", "plan.h", "model_pack.cpp")]
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", ROOT, "interp"], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(SO)
+    L.interp_create.restype = ctypes.c_void_p
+    L.interp_create.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]
+    L.interp_free.argtypes = [ctypes.c_void_p]
+    L.interp_run.argtypes = [ctypes.c_void_p] * 3
+    L.interp_n_ops.argtypes = [ctypes.c_void_p]
+    return L
+
+
+def run(L, path, mixes):
+    """mixes (B, 2, seg) -> (B, S, 2, seg)"""
+    B, _, seg = mixes.shape
+    h = L.interp_create(path.encode(), seg, B)
+    assert h
+    mi = np.ascontiguousarray(mixes.transpose(0, 2, 1)).astype(np.float32)
+    ns = 4 if "4s" in path else 6
+    out = np.zeros((B, ns, 2, seg), np.float32)
+    L.interp_run(h, mi.ctypes.data, out.ctypes.data)
+    L.interp_free(h)
+    return out
+
+
+@pytest.mark.parametrize("ns", [4, 6])
+def test_plan_matches_fp64_golden(ns, interp, golden_dir, tmp_models):
+    g = np.load(os.path.join(golden_dir, f"golden_seg_{ns}s.npz"))
+    out = run(interp, tmp_models[ns], g["mix"][None])
+    err = np.abs(out[0] - g["out"]).max() / np.abs(g["out"]).max()
+    assert err < 2e-5, err
+
+
+def test_plan_batch_equals_singles_and_oracle(interp, tmp_models):
+    rng = np.random.default_rng(3)
+    seg = 6000
+    mixes = (0.1 * rng.standard_normal((2, 2, seg))).astype(np.float32)
+    both = run(interp, tmp_models[6], mixes)
+    m = orc.OracleModel(tmp_models[6])
+    for b in range(2):
+        single = run(interp, tmp_models[6], mixes[b:b + 1])
+        assert np.abs(both[b] - single[0]).max() < 1e-6
+        ref = m.segment(mixes[b])
+        assert np.abs(both[b] - ref).max() / np.abs(ref).max() < 2e-5
+    m.close()
