@@ -112,6 +112,27 @@ extern "C" int dmx_model_n_sources(const dmx_model *m) { return m ? m->pm.n_sour
 extern "C" int dmx_model_n_tensors(const dmx_model *m) { return m ? m->pm.n_tensors : 0; }
 extern "C" int dmx_model_device(const dmx_model *m) { return m ? m->device : -1; }
 
+// alignment contract of the igemm staging loads (igemm.hip header) + kernel availability
+static bool validate_plan(const Plan &p, std::string &why)
+{
+    for (const Op &op : p.ops)
+    {
+        if (op.kind != OP_IGEMM)
+            continue;
+        const IGemm &g = op.g;
+        const bool al = ((i64)g.L0 * g.Cin) % 4 == 0 && (g.stride0 * g.Cin) % 4 == 0 && (g.pad0 * g.Cin) % 4 == 0 &&
+                        g.seg0 % 4 == 0 && g.K % 4 == 0 && g.xBatchStride % 4 == 0 && (g.S1 == 1 || g.seg0 % 16 == 0);
+        GemmArgs k{};
+        k.pro = g.pro, k.epi = g.epi;
+        if (!al || launch_igemm(g.cfg, k, nullptr, true) != 0)
+        {
+            why = "op " + op.name + (al ? ": no kernel instantiated for its (tile, prologue, epilogue)" : ": staging alignment contract violated");
+            return false;
+        }
+    }
+    return true;
+}
+
 static Plan *get_plan(dmx_ctx *c, int batch)
 {
     auto it = c->plans.find(batch);
@@ -139,6 +160,9 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     c->maxBatch = max_batch;
     HIPCHK(hipSetDevice(m->device));
     Plan *p = get_plan(c.get(), max_batch);
+    std::string why;
+    if (!validate_plan(*p, why))
+        return fail(DMX_ERR_ARG, "dmx_ctx_create: unsupported geometry (%s)", why.c_str());
     c->arenaFloats = p->arenaFloats;
     HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float)));
     HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float)));
@@ -204,7 +228,8 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s)
         k.rowstat = a(g.rowstat), k.NB = g.NB, k.table = w(g.table_w), k.tableScale = g.tableScale;
         k.Lout = g.Lout, k.Cout = g.Cout;
         k.M = (i64)g.B * g.P1 * g.P0;
-        launch_igemm(g.cfg, k, s);
+        if (launch_igemm(g.cfg, k, s) != 0)
+            fprintf(stderr, "[dmx] internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)\n", op.name.c_str(), g.cfg, g.pro, g.epi);
         break;
     }
     case OP_STATS_REDUCE:
@@ -529,7 +554,7 @@ extern "C" int dmx_debug_n_ops(const dmx_ctx *c)
 static void op_work(const Op &op, const char *&kernel, double &flops, double &bytes)
 {
     static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48",
-                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64"};
+                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64", "igemm_64x128"};
     flops = bytes = 0;
     kernel = "?";
     switch (op.kind)

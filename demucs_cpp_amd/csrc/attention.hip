@@ -118,17 +118,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
         f32x4 sT[4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
-        {
             sT[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // dim step outermost, key fragment innermost: 4 independent accumulator chains
 #pragma unroll
-            for (int kk = 0; kk < DF; ++kk)
-            {
-                const float4 kv = Ks[cur][4 * kk + h4][16 * kf + l15];
-                sT[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qf[kk].x, sT[kf], 0, 0, 0);
-                sT[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qf[kk].y, sT[kf], 0, 0, 0);
-                sT[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qf[kk].z, sT[kf], 0, 0, 0);
-                sT[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qf[kk].w, sT[kf], 0, 0, 0);
-            }
+        for (int kk = 0; kk < DF; ++kk)
+        {
+            float4 kv[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+                kv[kf] = Ks[cur][4 * kk + h4][16 * kf + l15];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+                {
+                    const float av = c == 0 ? kv[kf].x : (c == 1 ? kv[kf].y : (c == 2 ? kv[kf].z : kv[kf].w));
+                    const float bv = c == 0 ? qf[kk].x : (c == 1 ? qf[kk].y : (c == 2 ? qf[kk].z : qf[kk].w));
+                    sT[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, sT[kf], 0, 0, 0);
+                }
         }
         // ---- online softmax for query l15; lane holds keys 16kf + 4h4 + r
         float tmax = -INFINITY;
@@ -167,18 +174,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
             o[d][2] *= alpha;
             o[d][3] *= alpha;
         }
-        // ---- O^T += V^T P^T
+        // ---- O^T += V^T P^T  (key fragment outermost, dim fragment innermost: DF independent chains)
 #pragma unroll
-        for (int d = 0; d < DF; ++d)
+        for (int kf = 0; kf < 4; ++kf)
+        {
+            float4 vv[DF];
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-            {
-                const float4 vv = Vs[cur][4 * kf + h4][16 * d + l15];
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, sT[kf][0], o[d], 0, 0, 0);
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, sT[kf][1], o[d], 0, 0, 0);
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, sT[kf][2], o[d], 0, 0, 0);
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, sT[kf][3], o[d], 0, 0, 0);
-            }
+            for (int d = 0; d < DF; ++d)
+                vv[d] = Vs[cur][4 * kf + h4][16 * d + l15];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < DF; ++d)
+                {
+                    const float av = c == 0 ? vv[d].x : (c == 1 ? vv[d].y : (c == 2 ? vv[d].z : vv[d].w));
+                    o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT[kf][c], o[d], 0, 0, 0);
+                }
+        }
         if (next)
             store_tile(cur ^ 1);
         __syncthreads();

@@ -31,7 +31,9 @@ struct GemmArgs
     i64 M;
 };
 
-void launch_igemm(int cfg, const GemmArgs &a, hipStream_t s);
+// returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;
+// dry = true only checks availability
+int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
 
 struct ReduceArgs
 {

@@ -36,8 +36,9 @@ Geo make_geo(i64 seg)
 }
 
 
-int choose_cfg(i64 M, int N, bool paired)
+int choose_cfg(i64 M1, int N, bool paired)
 {
+    const i64 M = M1 * 4; // nominal batch of 4 segments in flight
     if (!paired)
     {
         if (N <= 16)
@@ -50,13 +51,13 @@ int choose_cfg(i64 M, int N, bool paired)
     else if (N <= 32)
         return 5;
     if (N <= 64)
-        return (M >= 128 * 200) ? 6 : 1;
+        return 6;
     if (N <= 96)
         return 2;
     if (N % 128 != 0 && N % 96 == 0)
         return 2;
     i64 tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-    return tiles128 >= 256 ? 0 : 1;
+    return tiles128 >= 256 ? 0 : 7;
 }
 
 namespace
@@ -99,8 +100,7 @@ struct Builder
         g.Kp = rup(g.K, 16);
         g.Np = rup(g.N, 16);
         g.xBatchStride = (i64)g.L1 * g.L0 * g.Cin;
-        i64 M = (i64)g.B * g.P1 * g.P0;
-        g.cfg = choose_cfg(M, g.N, paired);
+        g.cfg = choose_cfg((i64)g.P1 * g.P0, g.N, paired);
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
     }
     void push_gemm(const std::string &name, int stream, IGemm g)

@@ -226,9 +226,12 @@ static const TileCfg kTileCfgs[] = {
     {256, 16},  // 4
     {128, 32},  // 5
     {128, 64},  // 6
+    {64, 128},  // 7  same column decomposition as 0 (2 waves x 4 fragments): bit-identical row statistics
 };
-static const int kNumTileCfgs = 7;
-int choose_cfg(i64 M, int N, bool paired);
+static const int kNumTileCfgs = 8;
+// M1 = rows per batch element: the choice never depends on the batch size, so results are
+// bit-identical for any batching / sharding of segments
+int choose_cfg(i64 M1, int N, bool paired);
 
 struct Plan
 {

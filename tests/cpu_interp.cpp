@@ -462,3 +462,20 @@ extern "C"
         return -1;
     }
 }
+
+// lists the (tile cfg, prologue, epilogue, act, rowstat) combinations a plan uses (build tooling)
+extern "C" int interp_combos(void *h, int *out, int cap)
+{
+    Interp *it = (Interp *)h;
+    int n = 0;
+    for (auto &op : it->pl.ops)
+        if (op.kind == OP_IGEMM && n + 5 <= cap)
+        {
+            out[n++] = op.g.cfg;
+            out[n++] = op.g.pro;
+            out[n++] = op.g.epi;
+            out[n++] = op.g.act;
+            out[n++] = op.g.rowstat >= 0;
+        }
+    return n / 5;
+}
