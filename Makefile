@@ -33,3 +33,10 @@ clean:
 	rm -rf build $(LIB) tests/_build cli/*.main
 	$(MAKE) -C oracle clean
 .PHONY: all cli oracle interp clean
+
+# experiment builds: make variant NAME=timing FLAGS="-DDMX_TIMING -DDMX_PIN_LOADS=1"
+variant:
+	@mkdir -p build/$(NAME)
+	for f in igemm fft misc attention; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
+	for f in api plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so build/$(NAME)/*.o

@@ -100,6 +100,8 @@ def main():
         gathered = [torch.zeros_like(out) for _ in range(world)]
         track_out = torch.zeros((S, 2, n_track), device="cuda")
 
+    torch.cuda.synchronize()  # inputs produced on torch's stream are complete before the library's stream reads them
+
     def step():
         ctx.segment_device(mix.data_ptr(), out.data_ptr(), B)
         ctx.synchronize()  # the library runs on its own stream; hand over to torch's stream / RCCL

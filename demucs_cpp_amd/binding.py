@@ -14,7 +14,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "demucs_cpp_amd", "lib", "libdemucs_hip.so")
+LIB_PATH = os.environ.get("DMX_LIB", os.path.join(ROOT, "demucs_cpp_amd", "lib", "libdemucs_hip.so"))
 
 LAYOUT_EIGEN = 0
 LAYOUT_PLANAR = 1
@@ -28,7 +28,7 @@ EXPORTS = [
     "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_segment_infer",
     "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
-    "dmx_debug_profile",
+    "dmx_debug_profile", "dmx_debug_igemm_timing",
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def lib():
         L.dmx_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, fp]
         L.dmx_debug_n_ops.argtypes = [vp]
         L.dmx_debug_profile.argtypes = [vp, ci, ci, ctypes.c_char_p, ci]
+        L.dmx_debug_igemm_timing.argtypes = [vp, ci, ctypes.c_char_p, fp]
         _lib = L
     return _lib
 
@@ -213,3 +214,9 @@ class Context:
             nm, k, ms, fl, by = ln.split("\t")
             rows.append((nm, k, float(ms), float(fl), float(by)))
         return rows
+
+
+def igemm_timing(ctx: "Context", batch: int, op_name: str):
+    out = np.zeros(6, np.float64)
+    rc = lib().dmx_debug_igemm_timing(ctx.h, batch, op_name.encode(), out.ctypes.data)
+    return None if rc != 0 else out

@@ -205,7 +205,8 @@ extern "C" int dmx_ctx_synchronize(dmx_ctx *c)
 }
 
 // --------------------------------------------------------------------------- executor
-static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s)
+static unsigned long long *g_dbg = nullptr; // set only by dmx_debug_igemm_timing
+static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
 {
     float *A = c->dA;
     const float *W = c->m->dW;
@@ -228,6 +229,8 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s)
         k.rowstat = a(g.rowstat), k.NB = g.NB, k.table = w(g.table_w), k.tableScale = g.tableScale;
         k.Lout = g.Lout, k.Cout = g.Cout;
         k.M = (i64)g.B * g.P1 * g.P0;
+        k.zero = A + zeroOff;
+        k.dbg = g_dbg;
         if (launch_igemm(g.cfg, k, s) != 0)
             fprintf(stderr, "[dmx] internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)\n", op.name.c_str(), g.cfg, g.pro, g.epi);
         break;
@@ -289,7 +292,7 @@ static int run_plan(dmx_ctx *c, int batch)
     if (p->arenaFloats > c->arenaFloats)
         return fail(DMX_ERR_ARG, "internal: plan for batch %d exceeds the arena", batch);
     for (const Op &op : p->ops)
-        launch_op(c, op, c->stream);
+        launch_op(c, op, c->stream, p->zeroOff);
     c->lastBatch = batch;
     HIPCHK(hipGetLastError());
     return DMX_OK;
@@ -635,10 +638,10 @@ extern "C" int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, 
     {
         if (op.kind == OP_TAP)
             continue;
-        launch_op(c, op, c->stream); // warm
+        launch_op(c, op, c->stream, p->zeroOff); // warm
         (void)hipEventRecord(e0, c->stream);
         for (int r = 0; r < reps; ++r)
-            launch_op(c, op, c->stream);
+            launch_op(c, op, c->stream, p->zeroOff);
         (void)hipEventRecord(e1, c->stream);
         (void)hipEventSynchronize(e1);
         float t = 0.f;
@@ -659,4 +662,44 @@ extern "C" int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, 
         report[k] = 0;
     }
     return n;
+}
+
+// Phase timing of one igemm op (library must be built with -DDMX_TIMING): averages over all
+// workgroups of cycles spent in {issue loads, MFMA block, transform+ds_write, addresses,
+// barrier} per K-tile; out[5] = number of K-tiles. Returns 0 or -1.
+extern "C" int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name, double *out)
+{
+    if (!c || !op_name || !out)
+        return -1;
+    (void)hipSetDevice(c->m->device);
+    Plan *p = get_plan(c, batch);
+    for (const Op &op : p->ops)
+        if (op.kind == OP_IGEMM && op.name == op_name)
+        {
+            const IGemm &g = op.g;
+            const i64 M = (i64)g.B * g.P1 * g.P0;
+            const i64 nblk = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
+            unsigned long long *d = nullptr;
+            if (hipMalloc((void **)&d, nblk * 64) != hipSuccess)
+                return -1;
+            (void)hipMemset(d, 0, nblk * 64);
+            g_dbg = d;
+            launch_op(c, op, c->stream, p->zeroOff);
+            g_dbg = nullptr;
+            (void)hipStreamSynchronize(c->stream);
+            std::vector<unsigned long long> h((size_t)nblk * 8);
+            (void)hipMemcpy(h.data(), d, nblk * 64, hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            for (int i = 0; i < 6; ++i)
+                out[i] = 0;
+            for (i64 b = 0; b < nblk; ++b)
+                for (int i = 0; i < 6; ++i)
+                    out[i] += (double)h[(size_t)(b * 8 + i)];
+            for (int i = 0; i < 6; ++i)
+                out[i] /= (double)nblk;
+            for (int i = 0; i < 5; ++i)
+                out[i] /= out[5] > 0 ? out[5] : 1;
+            return 0;
+        }
+    return -1;
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
             const int idx = tid + i * 256;
             const int key = idx / DQ, dq = idx - key * DQ;
             if (idx < KT * DQ)
-                Ks[buf][dq][key] = kreg[i];
+                Ks[buf][dq][key ^ (2 * (dq & 3))] = kreg[i]; // XOR swizzle (see igemm.hip)
         }
 #pragma unroll
         for (int i = 0; i < VL; ++i)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
             float4 kv[4];
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
-                kv[kf] = Ks[cur][4 * kk + h4][16 * kf + l15];
+                kv[kf] = Ks[cur][4 * kk + h4][(16 * kf + l15) ^ (2 * h4)];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll

@@ -10,8 +10,9 @@
 // Math: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-exact fmaf chain, 157 TF
 // peak). Each lane reads ONE ds_read_b128 per fragment = 4 consecutive k of its row and
 // feeds 4 MFMAs; MFMA c pairs k-slot h = lane>>4 with real k = 4h + c for both
-// operands, so the 16x16x4 k-slots never need a shuffle. LDS layout [kq][row] float4
-// makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots (conflict free).
+// operands, so the 16x16x4 k-slots never need a shuffle. LDS layout [kq][row ^ swz(kq)] float4:
+// every 16-lane ds_read_b128 group hits 16 distinct 16-byte slots and every 8-lane
+// ds_write_b128 group (2 rows x 4 k-quads) 8 distinct ones (conflict free both ways).
 //
 // Tile = (WAVES_M*WMF*16) x (WAVES_N*WNF*16) x (16*KS), 256 threads. The staging loads
 // of tile t+1 are issued branch-free (clamped addresses, validity kept as a bit mask)
@@ -24,6 +25,11 @@
 // either entirely inside or entirely outside the valid input, and 16-byte aligned:
 // Cin*L0, Cin*stride0, Cin*pad0, seg0, K, xBatchStride are multiples of 4 elements.
 #include "kernels.h"
+#include <cstdlib>
+
+#ifndef DMX_PIN_LOADS
+#define DMX_PIN_LOADS 0
+#endif
 
 namespace dmx
 {
@@ -39,10 +45,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 {
     constexpr int BM = WAVES_M * WMF * 16;
     constexpr int BN = WAVES_N * WNF * 16;
-    constexpr int AR = BM / 64;              // A rows staged per thread (row = tid/4 + i*64)
-    constexpr int BR = (BN + 63) / 64;       // B rows staged per thread
+    constexpr int LPR = 4 * KS;              // lanes per staged row: one float4 each = the row's 16*KS floats (full 128-B lines at KS=2)
+    constexpr int RP = 256 / LPR;            // rows staged per pass
+    constexpr int SWM = KS == 1 ? 2 : 1;     // LDS swizzle: row ^ (k-quad * SWM), see store_tiles
+    constexpr int AR = BM / RP;              // A rows staged per thread (row = tid/LPR + i*RP)
+    constexpr int BR = (BN + RP - 1) / RP;   // B rows staged per thread
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
-    static_assert(BM % 64 == 0, "BM multiple of 64");
+    static_assert(BM % RP == 0, "BM multiple of the staging pass");
 
     __shared__ float4 As[2][4 * KS][BM];
     __shared__ float4 Bs[2][4 * KS][BN];
@@ -70,21 +79,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     }
     __syncthreads();
 
-    // ---- per-thread staging state: AR rows of A (same k-quad), BR rows of B
-    const int skq = tid & 3, srow = tid >> 2;
+    // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slane`
+    const int slane = tid % LPR, srow = tid / LPR;
     const i64 rowLen = (i64)p.L0 * p.Cin;
-    const float *aBase[AR];
+    const int rowLenI = (int)rowLen;
+    const float *aRow[AR]; // X + b*xBS + in1_0*rowLen + e0  (tap s1 = 0, k = 0)
     int aIn1[AR], aE0[AR];
     bool aRowOk[AR];
     float aMean[AR], aScale[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i)
     {
-        const int4 ri = rowinfo[srow + i * 64];
+        const int4 ri = rowinfo[srow + i * RP];
         aRowOk[i] = ri.w >= 0;
-        aBase[i] = p.X + (i64)ri.x * p.xBS;
         aIn1[i] = ri.y * p.stride1 - p.pad1;
-        aE0[i] = (ri.z * p.stride0 - p.pad0) * p.Cin + skq * 4;
+        aE0[i] = (ri.z * p.stride0 - p.pad0) * p.Cin;
+        aRow[i] = p.X + (i64)ri.x * p.xBS + (i64)aIn1[i] * rowLen + aE0[i];
         aMean[i] = 0.f, aScale[i] = 1.f;
         if (PRO == PRO_AFFINE && aRowOk[i])
         {
@@ -97,73 +107,88 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
             aScale[i] = p.proStats[ri.w * 4 + 1];
         }
     }
-    const float *bBase[BR];
+    const float *bRow[BR];
     bool bRowOk[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i)
     {
-        const int rl = srow + i * 64;
+        const int rl = srow + i * RP;
         const int n = n0 + rl;
         bRowOk[i] = rl < BN && n < p.Np;
-        bBase[i] = p.Wt + (i64)(bRowOk[i] ? n : 0) * p.Kp + skq * 4;
+        bRow[i] = p.Wt + (i64)(bRowOk[i] ? n : 0) * p.Kp;
     }
 
-    float4 aReg[KS][AR], bReg[KS][BR], gW[KS], gB[KS];
-    unsigned aMask = 0, bMask = 0;
+    float4 aReg[AR], bReg[BR], gW, gB;
     const int nk16 = p.Kp >> 4;
     const int nk = (nk16 + KS - 1) / KS;
 
-    // issue the global loads of K-tile kt: no branches, no use of the loaded values
-    auto load_tiles = [&](int kt) {
-        aMask = 0;
-        bMask = 0;
-#pragma unroll
-        for (int ch = 0; ch < KS; ++ch)
+    // Sequential K walk, one tile = 16*KS consecutive k; this lane stages k = kl .. kl+3.
+    // (s1, offb) = conv tap along axis 1 / offset inside its contiguous run, advanced per
+    // lane without division. Addresses of the NEXT tile are computed one iteration ahead
+    // (after the MFMA block), so the loop body starts with nothing but the global loads:
+    //   loads(t+1) ; MFMA(t) ; transform+ds_write(t+1) ; addresses(t+2) ; barrier
+    // Out-of-range chunks point at the zero page: PRO_NONE needs no masking at all.
+    int kl = slane * 4, s1 = 0, offb = slane * 4;
+    if (p.S1 > 1)
+        while (offb >= p.seg0)
         {
-            const int kbase = (kt * KS + ch) << 4;
-            const bool chOk = kbase < p.Kp;
-            int s1 = 0, offb = kbase;
-            if (p.S1 > 1)
-            {
-                s1 = kbase / p.seg0; // scalar
-                offb = kbase - s1 * p.seg0;
-            }
-            const int k = kbase + skq * 4;
+            offb -= p.seg0;
+            ++s1;
+        }
+    const float *addrA[AR], *addrB[BR], *addrG = p.zero;
+    unsigned maskNext = 0, maskHeld = 0;
+    auto compute_addrs = [&]() {
+        maskNext = 0;
+        const bool kOk = kl < p.K;
+        const int segOff = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
 #pragma unroll
-            for (int i = 0; i < AR; ++i)
-            {
-                const int in1 = aIn1[i] + s1 * p.dil1;
-                const i64 e = (i64)aE0[i] + offb;
-                const bool ok = chOk && aRowOk[i] && k < p.K && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLen;
-                const float *src = ok ? aBase[i] + (i64)in1 * rowLen + e : p.X;
-                aReg[ch][i] = *reinterpret_cast<const float4 *>(src);
-                aMask |= (ok ? 1u : 0u) << (ch * AR + i);
-            }
+        for (int i = 0; i < AR; ++i)
+        {
+            const int in1 = aIn1[i] + s1 * p.dil1;
+            const int e = aE0[i] + offb;
+            const bool ok = kOk && aRowOk[i] && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLenI;
+            addrA[i] = ok ? aRow[i] + segOff : p.zero;
+            maskNext |= (ok ? 1u : 0u) << i;
+        }
+        const bool kpOk = kl < p.Kp;
 #pragma unroll
-            for (int i = 0; i < BR; ++i)
-            {
-                const bool ok = chOk && bRowOk[i];
-                bReg[ch][i] = *reinterpret_cast<const float4 *>(ok ? bBase[i] + kbase : p.Wt);
-                bMask |= (ok ? 1u : 0u) << (ch * BR + i);
-            }
-            if (PRO == PRO_GN_GELU)
-            {
-                const int kk = (chOk && k < p.K) ? k : 0;
-                gW[ch] = *reinterpret_cast<const float4 *>(p.proW + kk);
-                gB[ch] = *reinterpret_cast<const float4 *>(p.proB + kk);
-            }
+        for (int i = 0; i < BR; ++i)
+            addrB[i] = (kpOk && bRowOk[i]) ? bRow[i] + kl : p.zero;
+        if (PRO == PRO_GN_GELU)
+            addrG = p.proW + (kOk ? kl : 0);
+        kl += 16 * KS;
+        offb += 16 * KS;
+        if (p.S1 > 1 && offb >= p.seg0)
+        {
+            offb -= p.seg0;
+            ++s1;
         }
     };
-    // prologue transform + zero fill + LDS write of the staged tile
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            aReg[i] = *reinterpret_cast<const float4 *>(addrA[i]);
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            bReg[i] = *reinterpret_cast<const float4 *>(addrB[i]);
+        if (PRO == PRO_GN_GELU)
+        {
+            gW = *reinterpret_cast<const float4 *>(addrG);
+            gB = *reinterpret_cast<const float4 *>(addrG + (p.proB - p.proW));
+        }
+        maskHeld = maskNext;
+    };
+    // prologue transform (+ zero fill where a transform would make padding non-zero) + LDS write.
+    // LDS image [k-quad q][row ^ q] float4: 8-lane ds_write_b128 groups (one row, 8 k-quads, or two
+    // rows x 4) and 16-lane ds_read_b128 groups (16 rows, k-quads {2j, 2j+1}) are conflict-free.
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int ch = 0; ch < KS; ++ch)
+        for (int i = 0; i < AR; ++i)
         {
-#pragma unroll
-            for (int i = 0; i < AR; ++i)
+            float4 v = aReg[i];
+            if (PRO != PRO_NONE)
             {
-                float4 v = aReg[ch][i];
-                const bool ok = (aMask >> (ch * AR + i)) & 1u;
+                const bool ok = (maskHeld >> i) & 1u;
                 if (PRO == PRO_AFFINE)
                 {
                     v.x = (v.x - aMean[i]) * aScale[i];
@@ -173,25 +198,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                 }
                 if (PRO == PRO_GN_GELU)
                 {
-                    v.x = gelu_f((v.x - aMean[i]) * aScale[i] * gW[ch].x + gB[ch].x);
-                    v.y = gelu_f((v.y - aMean[i]) * aScale[i] * gW[ch].y + gB[ch].y);
-                    v.z = gelu_f((v.z - aMean[i]) * aScale[i] * gW[ch].z + gB[ch].z);
-                    v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW[ch].w + gB[ch].w);
+                    v.x = gelu_f((v.x - aMean[i]) * aScale[i] * gW.x + gB.x);
+                    v.y = gelu_f((v.y - aMean[i]) * aScale[i] * gW.y + gB.y);
+                    v.z = gelu_f((v.z - aMean[i]) * aScale[i] * gW.z + gB.z);
+                    v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW.w + gB.w);
                 }
                 if (!ok)
                     v = make_float4(0.f, 0.f, 0.f, 0.f);
-                As[buf][ch * 4 + skq][srow + i * 64] = v;
             }
+            As[buf][slane][(srow + i * RP) ^ (slane * SWM)] = v;
+        }
 #pragma unroll
-            for (int i = 0; i < BR; ++i)
-            {
-                const int rl = srow + i * 64;
-                float4 v = bReg[ch][i];
-                if (!((bMask >> (ch * BR + i)) & 1u))
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rl < BN)
-                    Bs[buf][ch * 4 + skq][rl] = v;
-            }
+        for (int i = 0; i < BR; ++i)
+        {
+            const int rl = srow + i * RP;
+            if (BN % RP == 0 || rl < BN)
+                Bs[buf][slane][rl ^ (slane * SWM)] = bReg[i];
         }
     };
 
@@ -202,26 +224,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
         for (int j = 0; j < WNF; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(0);
+    compute_addrs();
+    issue_loads();
+    compute_addrs();
     store_tiles(0);
     __syncthreads();
     int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
+#ifdef DMX_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
+#define DMX_TSTAMP(i)                          \
+    do                                         \
+    {                                          \
+        __builtin_amdgcn_sched_barrier(0);     \
+        unsigned long long t_ = clock64();     \
+        tacc[i] += t_ - tprev;                 \
+        tprev = t_;                            \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#else
+#define DMX_TSTAMP(i)
+#endif
     for (int kt = 0; kt < nk; ++kt)
     {
-        const bool next = kt + 1 < nk;
-        if (next)
-            load_tiles(kt + 1);
+        issue_loads(); // tile kt+1 (zero page beyond the end: no branch)
+#if DMX_PIN_LOADS
+        __builtin_amdgcn_sched_barrier(0); // keep the loads AHEAD of the MFMA block (latency hiding)
+#endif
+        DMX_TSTAMP(0);
 #pragma unroll
         for (int ch = 0; ch < KS; ++ch)
         {
             float4 a[WMF], b[WNF];
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
-                a[i] = As[cur][ch * 4 + kq][wm * (WMF * 16) + i * 16 + l15];
+                a[i] = As[cur][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)];
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                b[j] = Bs[cur][ch * 4 + kq][wn * (WNF * 16) + j * 16 + l15];
+                b[j] = Bs[cur][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)];
             // k sub-step outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
             // MFMA has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
@@ -232,11 +272,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                     for (int j = 0; j < WNF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[i], c), f4c(b[j], c), acc[i][j], 0, 0, 0);
         }
-        if (next)
-            store_tiles(cur ^ 1);
+#if DMX_PIN_LOADS
+        __builtin_amdgcn_sched_barrier(0); // ... and their first use BEHIND it
+#endif
+        DMX_TSTAMP(1);
+        store_tiles(cur ^ 1);
+        DMX_TSTAMP(2);
+        compute_addrs();
+        DMX_TSTAMP(3);
         __syncthreads();
+        DMX_TSTAMP(4);
         cur ^= 1;
     }
+#ifdef DMX_TIMING
+    if (p.dbg && tid == 0)
+    {
+        unsigned long long *d = p.dbg + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 5; ++i)
+            d[i] = tacc[i];
+        d[5] = (unsigned long long)nk;
+    }
+#endif
 
     // ------------------------------------------------------------------ epilogue
     // C layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = (lane>>4)*4 + reg
@@ -244,6 +300,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     const int colBase = n0 + wn * (WNF * 16) + l15;
     float biasv[WNF];
     int trR[WNF], trC[WNF]; // EPI_TRCONV: column n -> (phase r, channel co)
+    float scalev[WNF], gnWv[WNF], gnBv[WNF];
 #pragma unroll
     for (int j = 0; j < WNF; ++j)
     {
@@ -254,6 +311,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
         {
             trR[j] = n / p.Cout;
             trC[j] = n - trR[j] * p.Cout;
+        }
+        scalev[j] = gnWv[j] = gnBv[j] = 0.f;
+        if (EPI == EPI_SCALE_RES && n < p.N)
+            scalev[j] = p.scale[n];
+        if (EPI == EPI_GN_GLU_SCALE_RES && n < p.N)
+        {
+            gnWv[j] = p.epiW[n];
+            gnBv[j] = p.epiB[n];
+            if ((j & 1) == 0)
+                scalev[j] = p.scale[(n >> 5) * 16 + (n & 15)];
         }
     }
 
@@ -268,8 +335,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
             const bool rowOk = ri.w >= 0;
             const i64 m = m0 + rl;
             float s = 0.f, ss = 0.f;
+            // residual operands of the whole row are loaded FIRST (independent loads in flight),
+            // then combined and stored: res may alias Y element-wise (in-place updates), and every
+            // element is read before the same lane overwrites it.
+            float resv[WNF];
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+                resv[j] = 0.f;
             if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
             {
+                if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
+                {
+#pragma unroll
+                    for (int j = 0; j < WNF; ++j)
+                    {
+                        const int n = colBase + j * 16;
+                        if (rowOk && n < p.N)
+                            resv[j] = p.res[m * p.ldy + n];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < WNF; ++j)
                 {
@@ -281,16 +365,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                         {
                             if (p.act)
                                 v = gelu_f(v);
-                            const i64 o = m * p.ldy + n;
-                            if (p.res)
-                                v += p.res[o];
-                            p.Y[o] = v;
+                            v += resv[j];
+                            p.Y[m * p.ldy + n] = v;
                         }
                         else if (EPI == EPI_SCALE_RES)
                         {
-                            const i64 o = m * p.ldy + n;
-                            v = p.res[o] + v * p.scale[n];
-                            p.Y[o] = v;
+                            v = resv[j] + v * scalev[j];
+                            p.Y[m * p.ldy + n] = v;
                         }
                         s += v;
                         ss += v * v;
@@ -307,6 +388,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                         mean = p.epiStats[ri.w * 4];
                         sc = p.epiStats[ri.w * 4 + 1];
                     }
+                    if (EPI == EPI_GN_GLU_SCALE_RES)
+                    {
+#pragma unroll
+                        for (int j = 0; j < WNF; j += 2)
+                        {
+                            const int na = colBase + j * 16;
+                            if (rowOk && na + 16 < p.N)
+                                resv[j] = p.res[m * p.ldy + (na >> 5) * 16 + (na & 15)];
+                        }
+                    }
+                    else if (p.table)
+                    {
+#pragma unroll
+                        for (int j = 0; j < WNF; j += 2)
+                        {
+                            const int na = colBase + j * 16;
+                            if (rowOk && na + 16 < p.N)
+                                resv[j] = p.tableScale * p.table[(i64)ri.z * (p.N >> 1) + (na >> 5) * 16 + (na & 15)];
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < WNF; j += 2)
                     {
@@ -316,43 +417,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                             float a = acc[i][j][r] + biasv[j];
                             float g = acc[i][j + 1][r] + biasv[j + 1];
                             const int c = (na >> 5) * 16 + (na & 15);
-                            const i64 o = m * p.ldy + c;
                             float v;
                             if (EPI == EPI_GN_GLU_SCALE_RES)
                             {
-                                a = (a - mean) * sc * p.epiW[na] + p.epiB[na];
-                                g = (g - mean) * sc * p.epiW[nb] + p.epiB[nb];
-                                v = p.res[o] + p.scale[c] * (a * sigmoid_f(g));
+                                a = (a - mean) * sc * gnWv[j] + gnBv[j];
+                                g = (g - mean) * sc * gnWv[j + 1] + gnBv[j + 1];
+                                v = resv[j] + scalev[j] * (a * sigmoid_f(g));
                             }
                             else
-                            {
-                                v = a * sigmoid_f(g);
-                                if (p.table)
-                                    v += p.tableScale * p.table[(i64)ri.z * (p.N >> 1) + c];
-                            }
-                            p.Y[o] = v;
+                                v = a * sigmoid_f(g) + resv[j];
+                            p.Y[m * p.ldy + c] = v;
                         }
                     }
                 }
             }
             else // EPI_TRCONV
             {
+                i64 offs[WNF];
 #pragma unroll
                 for (int j = 0; j < WNF; ++j)
                 {
                     const int n = colBase + j * 16;
                     const int jj = 4 * ri.z + trR[j] - 2;
-                    if (rowOk && n < p.N && jj >= 0 && jj < p.Lout)
+                    offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout)
+                                  ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j]
+                                  : -1;
+                }
+                if (p.res)
+                {
+#pragma unroll
+                    for (int j = 0; j < WNF; ++j)
+                        if (offs[j] >= 0)
+                            resv[j] = p.res[offs[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < WNF; ++j)
+                    if (offs[j] >= 0)
                     {
                         float v = acc[i][j][r] + biasv[j];
                         if (p.act)
                             v = gelu_f(v);
-                        const i64 o = (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j];
-                        if (p.res)
-                            v += p.res[o];
-                        p.Y[o] = v;
+                        p.Y[offs[j]] = v + resv[j];
                     }
-                }
             }
             if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
                 if (wantStats)
@@ -398,7 +504,8 @@ static void launch_one(const GemmArgs &a, hipStream_t s)
 {
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
-    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI>), grid, dim3(256), 0, s, a);
+    static const int padLds = getenv("DMX_IGEMM_PADLDS") ? atoi(getenv("DMX_IGEMM_PADLDS")) : 0; // experiment: limit residency
+    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI>), grid, dim3(256), padLds, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the
@@ -411,8 +518,25 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         if (!dry)                                       \
             launch_one<WM_, WN_, MF, NF, KS, PRO, EPI>(a, s); \
         return 0;
+    // A/B experiment knob: DMX_IGEMM_KS1=1 runs the 128x128 / 64x128 tiles with 16-deep K tiles
+    // (36 KB LDS, 3-4 workgroups per CU) instead of 32-deep (68 KB, 2 per CU)
+    static const bool ks1 = getenv("DMX_IGEMM_KS1") && atoi(getenv("DMX_IGEMM_KS1")) == 1;
+    if (ks1 && (cfg == 0 || cfg == 7))
+        cfg += 10;
     switch (cfg * 100 + a.pro * 10 + a.epi)
     {
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_GLU)
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_GLU)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 0: 128x128, cfg 7: 64x128 (same column decomposition)
         DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_LINEAR)
         DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_SCALE_RES)

@@ -29,6 +29,8 @@ struct GemmArgs
     float tableScale;
     int Lout, Cout;
     i64 M;
+    const float *zero; // >= 16 B of zeros, 16-byte aligned: target of out-of-range staging loads
+    unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
 };
 
 // returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;

@@ -219,6 +219,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
 
     // ------------------------------------------------------------------ constants
     // Hann window: periodic, PI literal and float math of src/dsp.hpp:59-75
+    pl.zeroOff = b.alloc(64);
     const i64 cWindow = b.alloc(4096);
     const i64 cTwiddle = b.alloc(2 * 2048);
     const int nfr = T + 4;

@@ -241,6 +241,7 @@ struct Plan
     i64 arenaFloats = 0;
     std::vector<float> constants; // first `constants.size()` floats of A
     std::vector<Op> ops;
+    i64 zeroOff = 0; // A: 64 floats that stay zero (igemm staging target for padding)
     i64 mixOff = 0; // A: [B][seg][2]
     i64 outOff = 0; // A: [B][S][2][seg]
 };

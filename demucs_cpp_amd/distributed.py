@@ -44,8 +44,15 @@ class HipBackend:
     def geometry(self, n, shift):
         return self.ctx.track_geometry(n, shift)  # (shifted_len, n_segments, stride)
 
+    @staticmethod
+    def _handover():
+        # the library runs on its own non-blocking HIP stream: everything torch produced on its
+        # current stream must be complete before the library reads it
+        torch.cuda.current_stream().synchronize()
+
     def stats(self, audio_il: torch.Tensor) -> torch.Tensor:
         st = torch.zeros(4, device=self.device)
+        self._handover()
         self.ctx.track_stats_device(audio_il.data_ptr(), audio_il.shape[0], st.data_ptr())
         return st
 
@@ -53,6 +60,7 @@ class HipBackend:
         """out[i] = hot path of segment seg_ids[i]; out: [len(seg_ids)][S][2][seg] on device."""
         n = audio_il.shape[0]
         mix = torch.empty((self.max_batch, self.seg, 2), device=self.device)
+        self._handover()
         for i0 in range(0, len(seg_ids), self.max_batch):
             ids = seg_ids[i0:i0 + self.max_batch]
             self.ctx.track_gather_device(audio_il.data_ptr(), n, stats.data_ptr(), shift, ids, mix.data_ptr())
@@ -61,6 +69,7 @@ class HipBackend:
 
     def overlap_add(self, seg_out: torch.Tensor, n_segments, n, shift, stats) -> torch.Tensor:
         out = torch.empty((self.S, 2, n), device=self.device)
+        self._handover()
         self.ctx.track_overlap_add_device(seg_out.data_ptr(), n_segments, n, shift, stats.data_ptr(), out.data_ptr())
         self.ctx.synchronize()
         return out

@@ -124,6 +124,8 @@ extern "C"
      * `report` with lines "name\tkernel\tms_per_launch\talgorithmic_flops\talgorithmic_bytes".
      * Returns the number of ops or -1. Leaves the activations undefined.                   */
     int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, int report_cap);
+    /* cycles per K-tile spent in the 5 phases of one igemm op (-DDMX_TIMING builds only)   */
+    int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name, double *out6);
 
 #ifdef __cplusplus
 }

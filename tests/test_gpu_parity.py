@@ -84,6 +84,7 @@ def test_batch_equals_singles_bitwise_and_layouts(dmx, tmp_models):
     m = dmx.Model(tmp_models[6]); ctx = dmx.Context(m, seg, B)
     d_mix = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).cuda()
     d_out = torch.zeros((B, 6, 2, seg), device="cuda")
+    torch.cuda.synchronize()
     ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
     ctx.synchronize()
     got = d_out.cpu().numpy()
@@ -142,6 +143,7 @@ def test_full_size_track_properties(dmx, tmp_models):
     stats = torch.tensor([0.25, 3.0, 0, 0], device="cuda")
     ones = torch.ones((nseg, S, 2, SEG_FULL), device="cuda")
     out = torch.empty((S, 2, n), device="cuda")
+    torch.cuda.synchronize()  # the library uses its own stream: hand over completed tensors
     ctx.track_overlap_add_device(ones.data_ptr(), nseg, n, shift, stats.data_ptr(), out.data_ptr())
     ctx.synchronize()
     assert torch.allclose(out, torch.full_like(out, 3.25), atol=1e-5)
