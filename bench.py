@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "4")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "12")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

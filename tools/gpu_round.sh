@@ -6,13 +6,13 @@ mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > gpurun_out/pytest_gpu.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > gpurun_out/smoke.log
 ( timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | tail -20 ) > gpurun_out/bench.log
-( timeout 600 python bench.py --steps 5 --warmup 2 --batch 1 --no-cpu-baseline 2>&1 | tail -5 ) > gpurun_out/bench_b1.log
-( timeout 600 python bench.py --steps 5 --warmup 2 --batch 8 --no-cpu-baseline 2>&1 | tail -5 ) > gpurun_out/bench_b8.log
+( timeout 600 python bench.py --steps 5 --warmup 2 --batch 1 --no-cpu-baseline --no-roofline 2>&1 | tail -5 ) > gpurun_out/bench_b1.log
+( timeout 600 python bench.py --steps 5 --warmup 2 --batch 4 --no-cpu-baseline --no-roofline 2>&1 | tail -5 ) > gpurun_out/bench_b4.log
 cd /tmp && export TMPDIR=/tmp
-( timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -15 ) > $R/gpurun_out/rocprof.log
+( timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --batch 12 2>&1 | tail -15 ) > $R/gpurun_out/rocprof.log
 cd $R
 find gpurun_out/prof -name "*stats*" | head
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -40 $f; done
 echo ---- pytest; cat gpurun_out/pytest_gpu.log
 echo ---- smoke; cat gpurun_out/smoke.log
-echo ---- bench; cat gpurun_out/bench.log gpurun_out/bench_b1.log gpurun_out/bench_b8.log
+echo ---- bench; cat gpurun_out/bench.log gpurun_out/bench_b1.log gpurun_out/bench_b4.log
