@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := demucs_cpp_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB := demucs_cpp_amd/lib/libdemucs_hip.so
-OBJS := $(addprefix build/,igemm.o fft.o misc.o attention.o api.o plan.o model_pack.o)
+OBJS := $(addprefix build/,igemm.o dgemm.o fft.o misc.o attention.o api.o plan.o model_pack.o)
 
 all: $(LIB) cli oracle interp
 
@@ -37,6 +37,6 @@ clean:
 # experiment builds: make variant NAME=timing FLAGS="-DDMX_TIMING -DDMX_PIN_LOADS=1"
 variant:
 	@mkdir -p build/$(NAME)
-	for f in igemm fft misc attention; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
+	for f in igemm dgemm fft misc attention; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
 	for f in api plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so build/$(NAME)/*.o

@@ -124,7 +124,8 @@ static bool validate_plan(const Plan &p, std::string &why)
                         g.seg0 % 4 == 0 && g.K % 4 == 0 && g.xBatchStride % 4 == 0 && (g.S1 == 1 || g.seg0 % 16 == 0);
         GemmArgs k{};
         k.pro = g.pro, k.epi = g.epi;
-        if (!al || launch_igemm(g.cfg, k, nullptr, true) != 0)
+        k.N = g.N, k.S1 = g.S1, k.seg0 = g.seg0, k.M = (i64)g.B * g.P1 * g.P0, k.L0 = g.L0, k.Cin = g.Cin;
+        if (!al || (g.cfg == kDirectCfg ? launch_dgemm(k, nullptr, true) : launch_igemm(g.cfg, k, nullptr, true)) != 0)
         {
             why = "op " + op.name + (al ? ": no kernel instantiated for its (tile, prologue, epilogue)" : ": staging alignment contract violated");
             return false;
@@ -231,7 +232,7 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff
         k.M = (i64)g.B * g.P1 * g.P0;
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
-        if (launch_igemm(g.cfg, k, s) != 0)
+        if ((g.cfg == kDirectCfg ? launch_dgemm(k, s) : launch_igemm(g.cfg, k, s)) != 0)
             fprintf(stderr, "[dmx] internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)\n", op.name.c_str(), g.cfg, g.pro, g.epi);
         break;
     }
@@ -557,7 +558,7 @@ extern "C" int dmx_debug_n_ops(const dmx_ctx *c)
 static void op_work(const Op &op, const char *&kernel, double &flops, double &bytes)
 {
     static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48",
-                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64", "igemm_64x128"};
+                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64", "igemm_64x128", "dgemm_direct"};
     flops = bytes = 0;
     kernel = "?";
     switch (op.kind)
@@ -678,6 +679,8 @@ extern "C" int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name
         {
             const IGemm &g = op.g;
             const i64 M = (i64)g.B * g.P1 * g.P0;
+            if (g.cfg == kDirectCfg)
+                return -1;
             const i64 nblk = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
             unsigned long long *d = nullptr;
             if (hipMalloc((void **)&d, nblk * 64) != hipSuccess)

@@ -1,0 +1,423 @@
+// dgemm.hip — "direct" fp32 MFMA implicit-GEMM for the HBM-bound layers of HTDemucs (gfx950).
+//
+// Level-0/1 layers (C = 48 / 96: first encoders, last decoders and their DConv branches;
+// /root/reference/src/encdec.cpp:8-164,166-361, src/layers.cpp:152-375) have K or N so small that
+// the whole weight matrix fits in one wave's registers and an A element is used by exactly one
+// wave. For those the LDS-staged tile kernel (igemm.hip) only adds barriers and a round trip
+// through LDS; they are bound by HBM, 57 % of the reference's unfused bytes.
+// Here:
+//   * one wave owns 16 output rows x ALL N columns at a time (NF column fragments of 16);
+//   * the weights are loaded ONCE per wave into registers, in MFMA B-operand order;
+//   * A is read straight from the channels-last activation into MFMA A-operand registers:
+//     lane (row = lane&15, h = lane>>4) loads 16 B at k = 16j + 4h of its row, so the four
+//     k-slots of v_mfma_f32_16x16x4_f32 take real k = 16j + 4h + c without any shuffle;
+//     runs that are not a multiple of 16 long (DConv hidden width 8 / 12) use k = RPL*h + c;
+//   * no LDS, no barrier; waves walk the row fragments with a grid stride (persistent);
+//   * the same prologues / epilogues as igemm.hip (plan.h), same row-statistics contract.
+// Semantics are specified by plan.h and tests/cpu_interp.cpp exactly like igemm.hip.
+#include "kernels.h"
+
+namespace dmx
+{
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dgelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dsigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f)
+{
+    return f.magic ? (__umulhi(n, f.magic) >> f.shift) : (n >> f.shift);
+}
+__device__ __forceinline__ float f4get(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+template <int NF, int S1, int SEG0, int PRO, int EPI>
+__global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const FastDiv dP0, const FastDiv dP1)
+{
+    constexpr int NV4 = SEG0 / 16;          // float4 steps per contiguous run
+    constexpr int RPL = (SEG0 % 16) / 4;    // remainder floats per lane (0, 2 or 3)
+    constexpr int NV4A = NV4 > 0 ? NV4 : 1; // array extents must not be 0
+    constexpr int RPLA = RPL > 0 ? RPL : 1;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, h = lane >> 4;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int rowLen = p.L0 * p.Cin;
+
+    // ---- weights -> registers (B operand: lane holds column n = 16 fj + l15)
+    float4 Bv[NF][S1][NV4A];
+    float Br[NF][S1][RPLA];
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj)
+    {
+        const int n = fj * 16 + l15;
+        const float *w = p.Wt + (i64)(n < p.Np ? n : 0) * p.Kp;
+        const bool nOk = n < p.Np;
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+        {
+#pragma unroll
+            for (int j = 0; j < NV4; ++j)
+                Bv[fj][s][j] = nOk ? *reinterpret_cast<const float4 *>(w + s * SEG0 + 16 * j + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < RPL; ++c)
+                Br[fj][s][c] = nOk ? w[s * SEG0 + 16 * NV4 + RPL * h + c] : 0.f;
+        }
+    }
+    // prologue constants of this lane's k positions (PRO_GN_GELU has S1 == 1)
+    float4 gW4[NV4A], gB4[NV4A];
+    float gWr[RPLA], gBr[RPLA];
+    if (PRO == PRO_GN_GELU)
+    {
+#pragma unroll
+        for (int j = 0; j < NV4; ++j)
+        {
+            gW4[j] = *reinterpret_cast<const float4 *>(p.proW + 16 * j + 4 * h);
+            gB4[j] = *reinterpret_cast<const float4 *>(p.proB + 16 * j + 4 * h);
+        }
+#pragma unroll
+        for (int c = 0; c < RPL; ++c)
+        {
+            gWr[c] = p.proW[16 * NV4 + RPL * h + c];
+            gBr[c] = p.proB[16 * NV4 + RPL * h + c];
+        }
+    }
+    // per-column epilogue constants. The MFMAs are issued with the operands SWAPPED (weights as A,
+    // activations as B), i.e. they produce C^T: lane (l15, h) then holds, for ITS OWN row m = 16 frag +
+    // l15, the 4 consecutive channels n = 16 fj + 4h + r -> float4 global accesses, no shuffles.
+    float4 biasv[NF], gnWv[NF], gnBv[NF], scalev[NF];
+    int trR[NF], trC[NF];
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj)
+    {
+        const int n = fj * 16 + 4 * h; // N, Np, Cout are multiples of 4
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        biasv[fj] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
+        scalev[fj] = gnWv[fj] = gnBv[fj] = z;
+        trR[fj] = trC[fj] = 0;
+        if (EPI == EPI_TRCONV)
+        {
+            trR[fj] = n / p.Cout;
+            trC[fj] = n - trR[fj] * p.Cout;
+        }
+        if (EPI == EPI_GN_GLU_SCALE_RES && n < p.N)
+        {
+            gnWv[fj] = *reinterpret_cast<const float4 *>(p.epiW + n);
+            gnBv[fj] = *reinterpret_cast<const float4 *>(p.epiB + n);
+            if ((fj & 1) == 0)
+                scalev[fj] = *reinterpret_cast<const float4 *>(p.scale + (fj >> 1) * 16 + 4 * h);
+        }
+    }
+
+    const int nfrag = (int)((p.M + 15) >> 4);
+    for (int frag = gwave; frag < nfrag; frag += nwaves)
+    {
+        // ---- A row of this lane
+        const unsigned m = (unsigned)frag * 16u + (unsigned)l15;
+        const bool rowOk = (i64)m < p.M;
+        const unsigned t1 = fdiv(rowOk ? m : 0u, dP0);
+        const int p0 = (int)((rowOk ? m : 0u) - t1 * (unsigned)p.P0);
+        const unsigned b = fdiv(t1, dP1);
+        const int p1 = (int)(t1 - b * (unsigned)p.P1);
+        const int grp = (int)b * p.G0 + (p.G0 > 1 ? p0 : 0);
+        float aMean = 0.f, aScale = 1.f;
+        if (PRO == PRO_AFFINE)
+        {
+            aMean = p.proStats[b * 4];
+            aScale = p.proStats[b * 4 + 1];
+        }
+        if (PRO == PRO_GN_GELU)
+        {
+            aMean = p.proStats[grp * 4];
+            aScale = p.proStats[grp * 4 + 1];
+        }
+        const int e0 = (p0 * p.stride0 - p.pad0) * p.Cin;
+        const float *xb = p.X + (i64)b * p.xBS;
+
+        // ---- all A loads of the fragment (independent, issued together)
+        float4 a4[S1][NV4A];
+        float ar[S1][RPLA];
+        bool ok4[S1][NV4A], okr[S1];
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+        {
+            const int in1 = p1 * p.stride1 + s * p.dil1 - p.pad1;
+            const bool ok1 = rowOk && in1 >= 0 && in1 < p.L1;
+            const float *rowp = xb + (i64)(ok1 ? in1 : 0) * rowLen;
+#pragma unroll
+            for (int j = 0; j < NV4; ++j)
+            {
+                const int e = e0 + 16 * j + 4 * h;
+                ok4[s][j] = ok1 && e >= 0 && e < rowLen;
+                a4[s][j] = *reinterpret_cast<const float4 *>(ok4[s][j] ? rowp + e : p.zero);
+            }
+            if (RPL > 0)
+            {
+                const int e = e0 + 16 * NV4 + RPL * h;
+                okr[s] = ok1 && e >= 0 && e < rowLen;
+                const float *src = okr[s] ? rowp + e : p.zero;
+#pragma unroll
+                for (int c = 0; c < RPL; ++c)
+                    ar[s][c] = src[c];
+            }
+        }
+        // ---- prologue + MFMAs
+        f32x4 acc[NF];
+#pragma unroll
+        for (int fj = 0; fj < NF; ++fj)
+            acc[fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+        {
+#pragma unroll
+            for (int j = 0; j < NV4; ++j)
+            {
+                float4 v = a4[s][j];
+                if (PRO == PRO_AFFINE)
+                {
+                    v.x = (v.x - aMean) * aScale, v.y = (v.y - aMean) * aScale;
+                    v.z = (v.z - aMean) * aScale, v.w = (v.w - aMean) * aScale;
+                }
+                if (PRO == PRO_GN_GELU)
+                {
+                    v.x = dgelu((v.x - aMean) * aScale * gW4[j].x + gB4[j].x);
+                    v.y = dgelu((v.y - aMean) * aScale * gW4[j].y + gB4[j].y);
+                    v.z = dgelu((v.z - aMean) * aScale * gW4[j].z + gB4[j].z);
+                    v.w = dgelu((v.w - aMean) * aScale * gW4[j].w + gB4[j].w);
+                }
+                if (PRO != PRO_NONE && !ok4[s][j])
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int fj = 0; fj < NF; ++fj)
+                        acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], c), f4get(v, c), acc[fj], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < RPL; ++c)
+            {
+                float v = ar[s][c];
+                if (PRO == PRO_AFFINE)
+                    v = (v - aMean) * aScale;
+                if (PRO == PRO_GN_GELU)
+                    v = dgelu((v - aMean) * aScale * gWr[c] + gBr[c]);
+                if (PRO != PRO_NONE && !okr[s])
+                    v = 0.f;
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                    acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(Br[fj][s][c], v, acc[fj], 0, 0, 0);
+            }
+        }
+        // ---- epilogue (C^T layout): this lane's row m, channels n = 16 fj + 4h + {0,1,2,3}
+        {
+            const i64 em = m;
+            const bool eOk = rowOk;
+            float s = 0.f, ss = 0.f;
+            if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY)
+            {
+                float4 resv[NF];
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                {
+                    const int n = fj * 16 + 4 * h;
+                    resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EPI == EPI_LINEAR && p.res && eOk && n < p.N)
+                        resv[fj] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + n);
+                }
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                {
+                    const int n = fj * 16 + 4 * h;
+                    if (eOk && n < p.N)
+                    {
+                        float4 v = make_float4(acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z,
+                                               acc[fj][3] + biasv[fj].w);
+                        if (EPI == EPI_LINEAR)
+                        {
+                            if (p.act)
+                                v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
+                            v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
+                            *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
+                        }
+                        s += (v.x + v.y) + (v.z + v.w);
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
+                }
+                if (p.rowstat)
+                {
+                    s += __shfl_xor(s, 16);
+                    ss += __shfl_xor(ss, 16);
+                    s += __shfl_xor(s, 32);
+                    ss += __shfl_xor(ss, 32);
+                    if (h == 0 && eOk)
+                        *reinterpret_cast<float2 *>(p.rowstat + em * 2) = make_float2(s, ss); // NB == 1
+                }
+            }
+            else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+            {
+                if constexpr (NF % 2 == 0)
+                {
+                    float mean = 0.f, sc = 1.f;
+                    if (EPI == EPI_GN_GLU_SCALE_RES && eOk)
+                    {
+                        mean = p.epiStats[grp * 4];
+                        sc = p.epiStats[grp * 4 + 1];
+                    }
+                    const int C = p.N >> 1;
+                    float4 resv[NF / 2];
+#pragma unroll
+                    for (int fj = 0; fj < NF; fj += 2)
+                    {
+                        const int c = (fj >> 1) * 16 + 4 * h;
+                        resv[fj >> 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (eOk && c < C)
+                        {
+                            if (EPI == EPI_GN_GLU_SCALE_RES)
+                                resv[fj >> 1] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + c);
+                            else if (p.table)
+                            {
+                                const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)p0 * C + c);
+                                resv[fj >> 1] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int fj = 0; fj < NF; fj += 2)
+                    {
+                        const int c = (fj >> 1) * 16 + 4 * h;
+                        if (eOk && c < C)
+                        {
+                            float av[4] = {acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z, acc[fj][3] + biasv[fj].w};
+                            float gv[4] = {acc[fj + 1][0] + biasv[fj + 1].x, acc[fj + 1][1] + biasv[fj + 1].y,
+                                           acc[fj + 1][2] + biasv[fj + 1].z, acc[fj + 1][3] + biasv[fj + 1].w};
+                            const float rv[4] = {resv[fj >> 1].x, resv[fj >> 1].y, resv[fj >> 1].z, resv[fj >> 1].w};
+                            float ov[4];
+                            if (EPI == EPI_GN_GLU_SCALE_RES)
+                            {
+                                const float gw[4] = {gnWv[fj].x, gnWv[fj].y, gnWv[fj].z, gnWv[fj].w};
+                                const float gb[4] = {gnBv[fj].x, gnBv[fj].y, gnBv[fj].z, gnBv[fj].w};
+                                const float hw[4] = {gnWv[fj + 1].x, gnWv[fj + 1].y, gnWv[fj + 1].z, gnWv[fj + 1].w};
+                                const float hb[4] = {gnBv[fj + 1].x, gnBv[fj + 1].y, gnBv[fj + 1].z, gnBv[fj + 1].w};
+                                const float sv[4] = {scalev[fj].x, scalev[fj].y, scalev[fj].z, scalev[fj].w};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                {
+                                    const float a = (av[r] - mean) * sc * gw[r] + gb[r];
+                                    const float g = (gv[r] - mean) * sc * hw[r] + hb[r];
+                                    ov[r] = rv[r] + sv[r] * (a * dsigmoid(g));
+                                }
+                            }
+                            else
+                            {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    ov[r] = av[r] * dsigmoid(gv[r]) + rv[r];
+                            }
+                            *reinterpret_cast<float4 *>(p.Y + em * p.ldy + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                        }
+                    }
+                }
+            }
+            else // EPI_TRCONV
+            {
+                i64 offs[NF];
+                float4 resv[NF];
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                {
+                    const int n = fj * 16 + 4 * h;
+                    const int jj = 4 * p0 + trR[fj] - 2;
+                    offs[fj] = (eOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)b * p.yBS + ((i64)p1 * p.Lout + jj) * p.ldy + trC[fj] : -1;
+                    resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (p.res)
+                {
+#pragma unroll
+                    for (int fj = 0; fj < NF; ++fj)
+                        if (offs[fj] >= 0)
+                            resv[fj] = *reinterpret_cast<const float4 *>(p.res + offs[fj]);
+                }
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                    if (offs[fj] >= 0)
+                    {
+                        float4 v = make_float4(acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z,
+                                               acc[fj][3] + biasv[fj].w);
+                        if (p.act)
+                            v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
+                        v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
+                        *reinterpret_cast<float4 *>(p.Y + offs[fj]) = v;
+                    }
+            }
+        }
+    }
+}
+
+static FastDiv make_fastdiv(unsigned d)
+{
+    FastDiv f;
+    f.magic = 0;
+    f.shift = 0;
+    if (d == 0)
+        d = 1;
+    if ((d & (d - 1)) == 0)
+    {
+        while ((1u << f.shift) < d)
+            ++f.shift;
+        return f;
+    }
+    unsigned s = 0;
+    while ((1ull << s) < d)
+        ++s;
+    f.magic = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d); // exact for n < 2^31
+    f.shift = s - 1;
+    return f;
+}
+
+template <int NF, int S1, int SEG0, int PRO, int EPI>
+static void launch_d(const GemmArgs &a, hipStream_t s)
+{
+    const int nfrag = (int)((a.M + 15) >> 4);
+    int blocks = (nfrag + 3) / 4;
+    if (blocks > 256 * 8)
+        blocks = 256 * 8; // persistent: 8 workgroups per CU at most, waves stride over fragments
+    hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI>), dim3(blocks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
+                       make_fastdiv((unsigned)a.P1));
+}
+
+// Direct kernel table. key = NF*1000000 + S1*100000 + SEG0*100 + PRO*10 + EPI. Returns 0, or -1 if
+// the combination is not instantiated (the plan then keeps the LDS-tiled igemm).
+int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
+{
+    const int NF = (a.N + 15) / 16;
+    if (a.M >= (1ll << 31) - 16 || (i64)a.L0 * a.Cin >= (1ll << 31))
+        return -1;
+#define DMX_D(NF_, S1_, SEG_, PRO_, EPI_)                                     \
+    case (NF_ * 1000000 + S1_ * 100000 + SEG_ * 100 + PRO_ * 10 + EPI_):      \
+        if (!dry)                                                             \
+            launch_d<NF_, S1_, SEG_, PRO_, EPI_>(a, s);                       \
+        return 0;
+    switch (NF * 1000000 + a.S1 * 100000 + a.seg0 * 100 + a.pro * 10 + a.epi)
+    {
+        // DConv k1: Conv1d(C -> C/8, k3): C = 48, 96
+        DMX_D(1, 3, 48, PRO_NONE, EPI_LINEAR)
+        DMX_D(1, 3, 96, PRO_NONE, EPI_LINEAR)
+        // DConv k2 / k3: hidden 8 (C=48) / 12 (C=96) -> 2C, statistics / final
+        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        // first encoder convs (z-norm prologue) k8 s4: Cin = 4 (freq), 2 (time)
+        DMX_D(3, 1, 32, PRO_AFFINE, EPI_LINEAR)
+        DMX_D(3, 1, 16, PRO_AFFINE, EPI_LINEAR)
+        // level-0 rewrites 48 -> 96 + GLU
+        DMX_D(6, 1, 48, PRO_NONE, EPI_GLU)
+        // last transposed convs 48 -> 4*Cout: Cout = 16 / 8 (4 sources), 24 / 12 (6 sources)
+        DMX_D(4, 1, 96, PRO_NONE, EPI_TRCONV)
+        DMX_D(2, 1, 96, PRO_NONE, EPI_TRCONV)
+        DMX_D(6, 1, 96, PRO_NONE, EPI_TRCONV)
+        DMX_D(3, 1, 96, PRO_NONE, EPI_TRCONV)
+    default:
+        return -1;
+    }
+#undef DMX_D
+}
+
+} // namespace dmx

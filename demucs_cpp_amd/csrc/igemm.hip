@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                 for (int i = 0; i < WMF; ++i)
 #pragma unroll
                     for (int j = 0; j < WNF; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[i], c), f4c(b[j], c), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(b[j], c), f4c(a[i], c), acc[i][j], 0, 0, 0); // operands swapped: C^T
         }
 #if DMX_PIN_LOADS
         __builtin_amdgcn_sched_barrier(0); // ... and their first use BEHIND it
@@ -295,183 +295,192 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #endif
 
     // ------------------------------------------------------------------ epilogue
-    // C layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = (lane>>4)*4 + reg
+    // The MFMAs were issued with the operands swapped (weights as A, activations as B), so each
+    // accumulator holds C^T: lane (l15, kq) owns row m = tile row 16 i + l15 and the 4 CONSECUTIVE
+    // channels n = 16 j + 4 kq + {0..3} -> one float4 global access per fragment, one row-info
+    // lookup per row fragment, 2-step cross-lane reduction for the row statistics.
     const bool wantStats = p.rowstat != nullptr;
-    const int colBase = n0 + wn * (WNF * 16) + l15;
-    float biasv[WNF];
-    int trR[WNF], trC[WNF]; // EPI_TRCONV: column n -> (phase r, channel co)
-    float scalev[WNF], gnWv[WNF], gnBv[WNF];
+    const int colBase = n0 + wn * (WNF * 16) + 4 * kq;
+    float4 biasv[WNF], scalev[WNF], gnWv[WNF], gnBv[WNF];
+    int trR[WNF], trC[WNF]; // EPI_TRCONV: column n -> (phase r, channel co); Cout % 4 == 0
 #pragma unroll
     for (int j = 0; j < WNF; ++j)
     {
         const int n = colBase + j * 16;
-        biasv[j] = n < p.N ? p.bias[n] : 0.f;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        biasv[j] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
+        scalev[j] = gnWv[j] = gnBv[j] = z;
         trR[j] = trC[j] = 0;
         if (EPI == EPI_TRCONV)
         {
             trR[j] = n / p.Cout;
             trC[j] = n - trR[j] * p.Cout;
         }
-        scalev[j] = gnWv[j] = gnBv[j] = 0.f;
         if (EPI == EPI_SCALE_RES && n < p.N)
-            scalev[j] = p.scale[n];
+            scalev[j] = *reinterpret_cast<const float4 *>(p.scale + n);
         if (EPI == EPI_GN_GLU_SCALE_RES && n < p.N)
         {
-            gnWv[j] = p.epiW[n];
-            gnBv[j] = p.epiB[n];
+            gnWv[j] = *reinterpret_cast<const float4 *>(p.epiW + n);
+            gnBv[j] = *reinterpret_cast<const float4 *>(p.epiB + n);
             if ((j & 1) == 0)
-                scalev[j] = p.scale[(n >> 5) * 16 + (n & 15)];
+                scalev[j] = *reinterpret_cast<const float4 *>(p.scale + (n >> 5) * 16 + (n & 15));
         }
     }
 
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
     {
+        const int rl = wm * (WMF * 16) + i * 16 + l15;
+        const int4 ri = rowinfo[rl];
+        const bool rowOk = ri.w >= 0;
+        const i64 m = m0 + rl;
+        float s = 0.f, ss = 0.f;
+        // residual operands of the whole row are loaded FIRST (independent loads in flight), then
+        // combined and stored: res may alias Y element-wise (in-place updates), every element is read
+        // before the same lane overwrites it.
+        float4 resv[WNF];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < WNF; ++j)
+            resv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
         {
-            const int rl = wm * (WMF * 16) + i * 16 + kq * 4 + r;
-            const int4 ri = rowinfo[rl];
-            const bool rowOk = ri.w >= 0;
-            const i64 m = m0 + rl;
-            float s = 0.f, ss = 0.f;
-            // residual operands of the whole row are loaded FIRST (independent loads in flight),
-            // then combined and stored: res may alias Y element-wise (in-place updates), and every
-            // element is read before the same lane overwrites it.
-            float resv[WNF];
+            if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
+            {
+#pragma unroll
+                for (int j = 0; j < WNF; ++j)
+                {
+                    const int n = colBase + j * 16;
+                    if (rowOk && n < p.N)
+                        resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + n);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                resv[j] = 0.f;
-            if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
             {
-                if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
+                const int n = colBase + j * 16;
+                if (rowOk && n < p.N)
                 {
-#pragma unroll
-                    for (int j = 0; j < WNF; ++j)
+                    float4 v = make_float4(acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
+                                           acc[i][j][3] + biasv[j].w);
+                    if (EPI == EPI_LINEAR)
                     {
-                        const int n = colBase + j * 16;
-                        if (rowOk && n < p.N)
-                            resv[j] = p.res[m * p.ldy + n];
+                        if (p.act)
+                            v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                        v.x += resv[j].x, v.y += resv[j].y, v.z += resv[j].z, v.w += resv[j].w;
+                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                {
-                    const int n = colBase + j * 16;
-                    float v = acc[i][j][r] + biasv[j];
-                    if (rowOk && n < p.N)
+                    else if (EPI == EPI_SCALE_RES)
                     {
-                        if (EPI == EPI_LINEAR)
-                        {
-                            if (p.act)
-                                v = gelu_f(v);
-                            v += resv[j];
-                            p.Y[m * p.ldy + n] = v;
-                        }
-                        else if (EPI == EPI_SCALE_RES)
-                        {
-                            v = resv[j] + v * scalev[j];
-                            p.Y[m * p.ldy + n] = v;
-                        }
-                        s += v;
-                        ss += v * v;
+                        v = make_float4(resv[j].x + v.x * scalev[j].x, resv[j].y + v.y * scalev[j].y, resv[j].z + v.z * scalev[j].z,
+                                        resv[j].w + v.w * scalev[j].w);
+                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
                     }
+                    s += (v.x + v.y) + (v.z + v.w);
+                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
             }
-            else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+            if (wantStats)
             {
-                if constexpr (WNF % 2 == 0)
+                s += __shfl_xor(s, 16);
+                ss += __shfl_xor(ss, 16);
+                s += __shfl_xor(s, 32);
+                ss += __shfl_xor(ss, 32);
+                if (kq == 0)
+                    rsum[rl][wn] = make_float2(s, ss);
+            }
+        }
+        else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+        {
+            if constexpr (WNF % 2 == 0)
+            {
+                float mean = 0.f, sc = 1.f;
+                if (EPI == EPI_GN_GLU_SCALE_RES && rowOk)
                 {
-                    float mean = 0.f, sc = 1.f;
-                    if (EPI == EPI_GN_GLU_SCALE_RES && rowOk)
-                    {
-                        mean = p.epiStats[ri.w * 4];
-                        sc = p.epiStats[ri.w * 4 + 1];
-                    }
-                    if (EPI == EPI_GN_GLU_SCALE_RES)
-                    {
+                    mean = p.epiStats[ri.w * 4];
+                    sc = p.epiStats[ri.w * 4 + 1];
+                }
 #pragma unroll
-                        for (int j = 0; j < WNF; j += 2)
+                for (int j = 0; j < WNF; j += 2)
+                {
+                    const int na = colBase + j * 16;
+                    const int c = (na >> 5) * 16 + (na & 15);
+                    if (rowOk && na + 16 < p.N)
+                    {
+                        if (EPI == EPI_GN_GLU_SCALE_RES)
+                            resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + c);
+                        else if (p.table)
                         {
-                            const int na = colBase + j * 16;
-                            if (rowOk && na + 16 < p.N)
-                                resv[j] = p.res[m * p.ldy + (na >> 5) * 16 + (na & 15)];
+                            const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)ri.z * (p.N >> 1) + c);
+                            resv[j] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
                         }
                     }
-                    else if (p.table)
-                    {
+                }
 #pragma unroll
-                        for (int j = 0; j < WNF; j += 2)
-                        {
-                            const int na = colBase + j * 16;
-                            if (rowOk && na + 16 < p.N)
-                                resv[j] = p.tableScale * p.table[(i64)ri.z * (p.N >> 1) + (na >> 5) * 16 + (na & 15)];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < WNF; j += 2)
+                for (int j = 0; j < WNF; j += 2)
+                {
+                    const int na = colBase + j * 16, nb = na + 16;
+                    if (rowOk && nb < p.N)
                     {
-                        const int na = colBase + j * 16, nb = na + 16;
-                        if (rowOk && nb < p.N)
+                        const int c = (na >> 5) * 16 + (na & 15);
+                        const float av[4] = {acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
+                                             acc[i][j][3] + biasv[j].w};
+                        const float gv[4] = {acc[i][j + 1][0] + biasv[j + 1].x, acc[i][j + 1][1] + biasv[j + 1].y,
+                                             acc[i][j + 1][2] + biasv[j + 1].z, acc[i][j + 1][3] + biasv[j + 1].w};
+                        const float rv[4] = {resv[j].x, resv[j].y, resv[j].z, resv[j].w};
+                        float ov[4];
+                        if (EPI == EPI_GN_GLU_SCALE_RES)
                         {
-                            float a = acc[i][j][r] + biasv[j];
-                            float g = acc[i][j + 1][r] + biasv[j + 1];
-                            const int c = (na >> 5) * 16 + (na & 15);
-                            float v;
-                            if (EPI == EPI_GN_GLU_SCALE_RES)
+                            const float gw[4] = {gnWv[j].x, gnWv[j].y, gnWv[j].z, gnWv[j].w};
+                            const float gb[4] = {gnBv[j].x, gnBv[j].y, gnBv[j].z, gnBv[j].w};
+                            const float hw[4] = {gnWv[j + 1].x, gnWv[j + 1].y, gnWv[j + 1].z, gnWv[j + 1].w};
+                            const float hb[4] = {gnBv[j + 1].x, gnBv[j + 1].y, gnBv[j + 1].z, gnBv[j + 1].w};
+                            const float sv[4] = {scalev[j].x, scalev[j].y, scalev[j].z, scalev[j].w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
                             {
-                                a = (a - mean) * sc * gnWv[j] + gnBv[j];
-                                g = (g - mean) * sc * gnWv[j + 1] + gnBv[j + 1];
-                                v = resv[j] + scalev[j] * (a * sigmoid_f(g));
+                                const float a = (av[r] - mean) * sc * gw[r] + gb[r];
+                                const float g = (gv[r] - mean) * sc * hw[r] + hb[r];
+                                ov[r] = rv[r] + sv[r] * (a * sigmoid_f(g));
                             }
-                            else
-                                v = a * sigmoid_f(g) + resv[j];
-                            p.Y[m * p.ldy + c] = v;
                         }
+                        else
+                        {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                ov[r] = av[r] * sigmoid_f(gv[r]) + rv[r];
+                        }
+                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
                     }
                 }
             }
-            else // EPI_TRCONV
+        }
+        else // EPI_TRCONV
+        {
+            i64 offs[WNF];
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
             {
-                i64 offs[WNF];
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                {
-                    const int n = colBase + j * 16;
-                    const int jj = 4 * ri.z + trR[j] - 2;
-                    offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout)
-                                  ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j]
-                                  : -1;
-                }
-                if (p.res)
-                {
-#pragma unroll
-                    for (int j = 0; j < WNF; ++j)
-                        if (offs[j] >= 0)
-                            resv[j] = p.res[offs[j]];
-                }
+                const int n = colBase + j * 16;
+                const int jj = 4 * ri.z + trR[j] - 2;
+                offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j] : -1;
+            }
+            if (p.res)
+            {
 #pragma unroll
                 for (int j = 0; j < WNF; ++j)
                     if (offs[j] >= 0)
-                    {
-                        float v = acc[i][j][r] + biasv[j];
-                        if (p.act)
-                            v = gelu_f(v);
-                        p.Y[offs[j]] = v + resv[j];
-                    }
+                        resv[j] = *reinterpret_cast<const float4 *>(p.res + offs[j]);
             }
-            if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
-                if (wantStats)
-                {
-                    // reduce over the 16 lanes that share this row (same lane>>4)
 #pragma unroll
-                    for (int off = 1; off < 16; off <<= 1)
-                    {
-                        s += __shfl_xor(s, off);
-                        ss += __shfl_xor(ss, off);
-                    }
-                    if (l15 == 0)
-                        rsum[rl][wn] = make_float2(s, ss);
+            for (int j = 0; j < WNF; ++j)
+                if (offs[j] >= 0)
+                {
+                    float4 v = make_float4(acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
+                                           acc[i][j][3] + biasv[j].w);
+                    if (p.act)
+                        v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                    v.x += resv[j].x, v.y += resv[j].y, v.z += resv[j].z, v.w += resv[j].w;
+                    *reinterpret_cast<float4 *>(p.Y + offs[j]) = v;
                 }
         }
     }
@@ -518,25 +527,8 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         if (!dry)                                       \
             launch_one<WM_, WN_, MF, NF, KS, PRO, EPI>(a, s); \
         return 0;
-    // A/B experiment knob: DMX_IGEMM_KS1=1 runs the 128x128 / 64x128 tiles with 16-deep K tiles
-    // (36 KB LDS, 3-4 workgroups per CU) instead of 32-deep (68 KB, 2 per CU)
-    static const bool ks1 = getenv("DMX_IGEMM_KS1") && atoi(getenv("DMX_IGEMM_KS1")) == 1;
-    if (ks1 && (cfg == 0 || cfg == 7))
-        cfg += 10;
     switch (cfg * 100 + a.pro * 10 + a.epi)
     {
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_SCALE_RES)
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_GLU)
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_CASE(10, 2, 2, 4, 4, 1, PRO_GN_GELU, EPI_STATS_ONLY)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_SCALE_RES)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_GLU)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_CASE(17, 2, 2, 2, 4, 1, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 0: 128x128, cfg 7: 64x128 (same column decomposition)
         DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_LINEAR)
         DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_SCALE_RES)

@@ -33,6 +33,14 @@ struct GemmArgs
     unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
 };
 
+struct FastDiv // n / d for n < 2^31: magic == 0 ? n >> shift : umulhi(n, magic) >> shift
+{
+    unsigned magic, shift;
+};
+// direct (register-resident weights, no LDS) kernels for the HBM-bound layers; -1 if the shape is
+// not in their table
+int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
+
 // returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;
 // dry = true only checks availability
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);

@@ -60,6 +60,31 @@ int choose_cfg(i64 M1, int N, bool paired)
     return tiles128 >= 256 ? 0 : 7;
 }
 
+bool direct_available(int N, int S1, int seg0, int pro, int epi)
+{
+    const int NF = (N + 15) / 16;
+    const int key = NF * 1000000 + S1 * 100000 + seg0 * 100 + pro * 10 + epi;
+    static const int keys[] = {
+        1 * 1000000 + 3 * 100000 + 48 * 100 + PRO_NONE * 10 + EPI_LINEAR,
+        1 * 1000000 + 3 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_LINEAR,
+        6 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_STATS_ONLY,
+        6 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
+        12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_STATS_ONLY,
+        12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
+        3 * 1000000 + 1 * 100000 + 32 * 100 + PRO_AFFINE * 10 + EPI_LINEAR,
+        3 * 1000000 + 1 * 100000 + 16 * 100 + PRO_AFFINE * 10 + EPI_LINEAR,
+        6 * 1000000 + 1 * 100000 + 48 * 100 + PRO_NONE * 10 + EPI_GLU,
+        4 * 1000000 + 1 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_TRCONV,
+        2 * 1000000 + 1 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_TRCONV,
+        6 * 1000000 + 1 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_TRCONV,
+        3 * 1000000 + 1 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_TRCONV,
+    };
+    for (int k : keys)
+        if (k == key)
+            return true;
+    return false;
+}
+
 namespace
 {
 struct Builder
@@ -101,6 +126,10 @@ struct Builder
         g.Np = rup(g.N, 16);
         g.xBatchStride = (i64)g.L1 * g.L0 * g.Cin;
         g.cfg = choose_cfg((i64)g.P1 * g.P0, g.N, paired);
+        // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
+        if (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
+            (g.epi == EPI_STATS_ONLY && direct_available(g.N, g.S1, g.seg0, g.pro, EPI_GN_GLU_SCALE_RES)))
+            g.cfg = kDirectCfg;
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
     }
     void push_gemm(const std::string &name, int stream, IGemm g)

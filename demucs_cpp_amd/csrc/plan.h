@@ -227,8 +227,12 @@ static const TileCfg kTileCfgs[] = {
     {128, 32},  // 5
     {128, 64},  // 6
     {64, 128},  // 7  same column decomposition as 0 (2 waves x 4 fragments): bit-identical row statistics
+    {16, 256},  // 8  kDirectCfg: dgemm.hip direct kernels, one wave owns 16 rows x all columns (NB = 1)
 };
-static const int kNumTileCfgs = 8;
+static const int kNumTileCfgs = 9;
+static const int kDirectCfg = 8;
+// shapes served by the direct kernels (must match the table in dgemm.hip)
+bool direct_available(int N, int S1, int seg0, int pro, int epi);
 // M1 = rows per batch element: the choice never depends on the batch size, so results are
 // bit-identical for any batching / sharding of segments
 int choose_cfg(i64 M1, int N, bool paired);
