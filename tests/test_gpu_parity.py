@@ -181,3 +181,31 @@ def test_argument_errors(dmx, tmp_models):
     with pytest.raises(dmx.DmxError):
         ctx.segment_device(1, 1, 2)  # batch > max_batch
     ctx.close(); m.close()
+
+
+def test_cli_drop_in(dmx, tmp_models, golden_dir, tmp_path):
+    """cli/demucs.cpp.main keeps the reference's argv contract and output naming
+    (/root/reference/cli-apps/demucs.cpp:107-232) and produces the same stems as the library API."""
+    import subprocess
+    from wavio import read_wav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cli", "demucs.cpp.main")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    wav = os.path.join(golden_dir, "gspi_stereo_short.wav")  # reference fixture (LIST chunk before data)
+    out_dir = tmp_path / "stems"
+    env = dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2")  # shift of .github/SDR_scores.md:21
+    r = subprocess.run([exe, tmp_models[4], wav, str(out_dir)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "demucs_model_load returned true" in r.stdout
+    _, audio = read_wav(wav)
+    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 2)
+    ref = ctx.track(audio, 1337)
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        rate, stem = read_wav(str(out_dir / f"target_{i}_{name}.wav"))
+        assert rate == 44100 and stem.shape == audio.shape
+        assert np.array_equal(stem, ref[i])
+    # wrong usage and unreadable model keep the reference's behaviour (exit 1)
+    assert subprocess.run([exe], capture_output=True).returncode == 1
+    assert subprocess.run([exe, "/nonexistent.bin", wav, str(out_dir)], capture_output=True).returncode == 1
+    ctx.close(); m.close()
