@@ -82,59 +82,86 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
     // per-column epilogue constants. The MFMAs are issued with the operands SWAPPED (weights as A,
     // activations as B), i.e. they produce C^T: lane (l15, h) then holds, for ITS OWN row m = 16 frag +
     // l15, the 4 consecutive channels n = 16 fj + 4h + r -> float4 global accesses, no shuffles.
-    float4 biasv[NF], gnWv[NF], gnBv[NF], scalev[NF];
+    // The GroupNorm+GLU epilogue needs 3.5 float4 constants per column fragment: those live in LDS
+    // (broadcast ds_read_b128, 16 lanes per address) so that the kernel keeps >= 4 waves per SIMD.
+    constexpr bool CST_LDS = EPI == EPI_GN_GLU_SCALE_RES;
+    __shared__ float4 cst[CST_LDS ? 4 : 1][NF][4]; // [bias | gn weight | gn bias | layer scale][fj][h]
+    float4 biasv[CST_LDS ? 1 : NF];
     int trR[NF], trC[NF];
+    if (CST_LDS)
+    {
+        for (int i = threadIdx.x; i < NF * 4; i += 256)
+        {
+            const int fj = i >> 2, hh = i & 3, n = fj * 16 + 4 * hh;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = n < p.N;
+            cst[0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
+            cst[CST_LDS ? 1 : 0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.epiW + n) : z;
+            cst[CST_LDS ? 2 : 0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.epiB + n) : z;
+            cst[CST_LDS ? 3 : 0][fj][hh] = (ok && (fj & 1) == 0) ? *reinterpret_cast<const float4 *>(p.scale + (fj >> 1) * 16 + 4 * hh) : z;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int fj = 0; fj < NF; ++fj)
     {
         const int n = fj * 16 + 4 * h; // N, Np, Cout are multiples of 4
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        biasv[fj] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
-        scalev[fj] = gnWv[fj] = gnBv[fj] = z;
+        if (!CST_LDS)
+            biasv[fj] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         trR[fj] = trC[fj] = 0;
         if (EPI == EPI_TRCONV)
         {
             trR[fj] = n / p.Cout;
             trC[fj] = n - trR[fj] * p.Cout;
         }
-        if (EPI == EPI_GN_GLU_SCALE_RES && n < p.N)
-        {
-            gnWv[fj] = *reinterpret_cast<const float4 *>(p.epiW + n);
-            gnBv[fj] = *reinterpret_cast<const float4 *>(p.epiB + n);
-            if ((fj & 1) == 0)
-                scalev[fj] = *reinterpret_cast<const float4 *>(p.scale + (fj >> 1) * 16 + 4 * h);
-        }
     }
 
-    const int nfrag = (int)((p.M + 15) >> 4);
-    for (int frag = gwave; frag < nfrag; frag += nwaves)
+    // ---- software pipeline over this wave's row fragments: everything fragment f+1 needs from memory
+    // (A runs, normalisation statistics of its row group, residual / table operands) is requested
+    // BEFORE the MFMAs and the epilogue of fragment f, so a wave always has one fragment in flight.
+    constexpr int NRES = (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES) ? (NF + 1) / 2 : 1;
+    struct Stage
     {
-        // ---- A row of this lane
+        unsigned m, b;
+        int p0, p1;
+        bool rowOk;
+        float aMean, aScale, eMean, eSc;
+        float4 a4[S1][NV4A];
+        float ar[S1][RPLA];
+        unsigned ok4, okr; // validity bits [s * NV4 + j] / [s]
+        float4 resv[NRES];
+    };
+    const int nfrag = (int)((p.M + 15) >> 4);
+    const int C2 = p.N >> 1;
+    auto fetch = [&](int frag, Stage &st) {
         const unsigned m = (unsigned)frag * 16u + (unsigned)l15;
-        const bool rowOk = (i64)m < p.M;
-        const unsigned t1 = fdiv(rowOk ? m : 0u, dP0);
-        const int p0 = (int)((rowOk ? m : 0u) - t1 * (unsigned)p.P0);
+        const bool rowOk = frag < nfrag && (i64)m < p.M;
+        const unsigned mm = rowOk ? m : 0u;
+        const unsigned t1 = fdiv(mm, dP0);
+        const int p0 = (int)(mm - t1 * (unsigned)p.P0);
         const unsigned b = fdiv(t1, dP1);
         const int p1 = (int)(t1 - b * (unsigned)p.P1);
         const int grp = (int)b * p.G0 + (p.G0 > 1 ? p0 : 0);
-        float aMean = 0.f, aScale = 1.f;
+        st.m = m, st.b = b, st.p0 = p0, st.p1 = p1, st.rowOk = rowOk;
+        st.aMean = 0.f, st.aScale = 1.f, st.eMean = 0.f, st.eSc = 1.f;
         if (PRO == PRO_AFFINE)
         {
-            aMean = p.proStats[b * 4];
-            aScale = p.proStats[b * 4 + 1];
+            st.aMean = p.proStats[b * 4];
+            st.aScale = p.proStats[b * 4 + 1];
         }
         if (PRO == PRO_GN_GELU)
         {
-            aMean = p.proStats[grp * 4];
-            aScale = p.proStats[grp * 4 + 1];
+            st.aMean = p.proStats[grp * 4];
+            st.aScale = p.proStats[grp * 4 + 1];
+        }
+        if (EPI == EPI_GN_GLU_SCALE_RES)
+        {
+            st.eMean = p.epiStats[grp * 4];
+            st.eSc = p.epiStats[grp * 4 + 1];
         }
         const int e0 = (p0 * p.stride0 - p.pad0) * p.Cin;
         const float *xb = p.X + (i64)b * p.xBS;
-
-        // ---- all A loads of the fragment (independent, issued together)
-        float4 a4[S1][NV4A];
-        float ar[S1][RPLA];
-        bool ok4[S1][NV4A], okr[S1];
+        st.ok4 = 0, st.okr = 0;
 #pragma unroll
         for (int s = 0; s < S1; ++s)
         {
@@ -145,19 +172,42 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
             for (int j = 0; j < NV4; ++j)
             {
                 const int e = e0 + 16 * j + 4 * h;
-                ok4[s][j] = ok1 && e >= 0 && e < rowLen;
-                a4[s][j] = *reinterpret_cast<const float4 *>(ok4[s][j] ? rowp + e : p.zero);
+                const bool ok = ok1 && e >= 0 && e < rowLen;
+                st.ok4 |= (ok ? 1u : 0u) << (s * NV4 + j);
+                st.a4[s][j] = *reinterpret_cast<const float4 *>(ok ? rowp + e : p.zero);
             }
             if (RPL > 0)
             {
                 const int e = e0 + 16 * NV4 + RPL * h;
-                okr[s] = ok1 && e >= 0 && e < rowLen;
-                const float *src = okr[s] ? rowp + e : p.zero;
+                const bool ok = ok1 && e >= 0 && e < rowLen;
+                st.okr |= (ok ? 1u : 0u) << s;
+                const float *src = ok ? rowp + e : p.zero;
 #pragma unroll
                 for (int c = 0; c < RPL; ++c)
-                    ar[s][c] = src[c];
+                    st.ar[s][c] = src[c];
             }
         }
+#pragma unroll
+        for (int r = 0; r < NRES; ++r)
+            st.resv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+        {
+#pragma unroll
+            for (int r = 0; r < NRES; ++r)
+            {
+                const int c = r * 16 + 4 * h;
+                if (rowOk && c < C2)
+                {
+                    if (EPI == EPI_GN_GLU_SCALE_RES) // res may alias Y: rows are private to one lane, read before written
+                        st.resv[r] = *reinterpret_cast<const float4 *>(p.res + (i64)m * p.ldy + c);
+                    else if (p.table)
+                        st.resv[r] = *reinterpret_cast<const float4 *>(p.table + (i64)p0 * C2 + c);
+                }
+            }
+        }
+    };
+    auto compute = [&](const Stage &st) {
+        const float aMean = st.aMean, aScale = st.aScale;
         // ---- prologue + MFMAs
         f32x4 acc[NF];
 #pragma unroll
@@ -169,7 +219,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
 #pragma unroll
             for (int j = 0; j < NV4; ++j)
             {
-                float4 v = a4[s][j];
+                float4 v = st.a4[s][j];
                 if (PRO == PRO_AFFINE)
                 {
                     v.x = (v.x - aMean) * aScale, v.y = (v.y - aMean) * aScale;
@@ -182,7 +232,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                     v.z = dgelu((v.z - aMean) * aScale * gW4[j].z + gB4[j].z);
                     v.w = dgelu((v.w - aMean) * aScale * gW4[j].w + gB4[j].w);
                 }
-                if (PRO != PRO_NONE && !ok4[s][j])
+                if (PRO != PRO_NONE && !((st.ok4 >> (s * NV4 + j)) & 1u))
                     v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -193,12 +243,12 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
 #pragma unroll
             for (int c = 0; c < RPL; ++c)
             {
-                float v = ar[s][c];
+                float v = st.ar[s][c];
                 if (PRO == PRO_AFFINE)
                     v = (v - aMean) * aScale;
                 if (PRO == PRO_GN_GELU)
                     v = dgelu((v - aMean) * aScale * gWr[c] + gBr[c]);
-                if (PRO != PRO_NONE && !okr[s])
+                if (PRO != PRO_NONE && !((st.okr >> s) & 1u))
                     v = 0.f;
 #pragma unroll
                 for (int fj = 0; fj < NF; ++fj)
@@ -206,147 +256,138 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
             }
         }
         // ---- epilogue (C^T layout): this lane's row m, channels n = 16 fj + 4h + {0,1,2,3}
+        const i64 em = st.m;
+        const bool eOk = st.rowOk;
+        const int p0 = st.p0, p1 = st.p1;
+        const unsigned b = st.b;
+        float s = 0.f, ss = 0.f;
+        if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY)
         {
-            const i64 em = m;
-            const bool eOk = rowOk;
-            float s = 0.f, ss = 0.f;
-            if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY)
+            float4 resv[NF];
+#pragma unroll
+            for (int fj = 0; fj < NF; ++fj)
             {
-                float4 resv[NF];
-#pragma unroll
-                for (int fj = 0; fj < NF; ++fj)
-                {
-                    const int n = fj * 16 + 4 * h;
-                    resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (EPI == EPI_LINEAR && p.res && eOk && n < p.N)
-                        resv[fj] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + n);
-                }
-#pragma unroll
-                for (int fj = 0; fj < NF; ++fj)
-                {
-                    const int n = fj * 16 + 4 * h;
-                    if (eOk && n < p.N)
-                    {
-                        float4 v = make_float4(acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z,
-                                               acc[fj][3] + biasv[fj].w);
-                        if (EPI == EPI_LINEAR)
-                        {
-                            if (p.act)
-                                v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
-                            v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
-                            *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
-                        }
-                        s += (v.x + v.y) + (v.z + v.w);
-                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                    }
-                }
-                if (p.rowstat)
-                {
-                    s += __shfl_xor(s, 16);
-                    ss += __shfl_xor(ss, 16);
-                    s += __shfl_xor(s, 32);
-                    ss += __shfl_xor(ss, 32);
-                    if (h == 0 && eOk)
-                        *reinterpret_cast<float2 *>(p.rowstat + em * 2) = make_float2(s, ss); // NB == 1
-                }
+                const int n = fj * 16 + 4 * h;
+                resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (EPI == EPI_LINEAR && p.res && eOk && n < p.N)
+                    resv[fj] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + n);
             }
-            else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+#pragma unroll
+            for (int fj = 0; fj < NF; ++fj)
             {
-                if constexpr (NF % 2 == 0)
+                const int n = fj * 16 + 4 * h;
+                if (eOk && n < p.N)
                 {
-                    float mean = 0.f, sc = 1.f;
-                    if (EPI == EPI_GN_GLU_SCALE_RES && eOk)
+                    const float4 bi = biasv[CST_LDS ? 0 : fj];
+                    float4 v = make_float4(acc[fj][0] + bi.x, acc[fj][1] + bi.y, acc[fj][2] + bi.z, acc[fj][3] + bi.w);
+                    if (EPI == EPI_LINEAR)
                     {
-                        mean = p.epiStats[grp * 4];
-                        sc = p.epiStats[grp * 4 + 1];
-                    }
-                    const int C = p.N >> 1;
-                    float4 resv[NF / 2];
-#pragma unroll
-                    for (int fj = 0; fj < NF; fj += 2)
-                    {
-                        const int c = (fj >> 1) * 16 + 4 * h;
-                        resv[fj >> 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (eOk && c < C)
-                        {
-                            if (EPI == EPI_GN_GLU_SCALE_RES)
-                                resv[fj >> 1] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + c);
-                            else if (p.table)
-                            {
-                                const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)p0 * C + c);
-                                resv[fj >> 1] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int fj = 0; fj < NF; fj += 2)
-                    {
-                        const int c = (fj >> 1) * 16 + 4 * h;
-                        if (eOk && c < C)
-                        {
-                            float av[4] = {acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z, acc[fj][3] + biasv[fj].w};
-                            float gv[4] = {acc[fj + 1][0] + biasv[fj + 1].x, acc[fj + 1][1] + biasv[fj + 1].y,
-                                           acc[fj + 1][2] + biasv[fj + 1].z, acc[fj + 1][3] + biasv[fj + 1].w};
-                            const float rv[4] = {resv[fj >> 1].x, resv[fj >> 1].y, resv[fj >> 1].z, resv[fj >> 1].w};
-                            float ov[4];
-                            if (EPI == EPI_GN_GLU_SCALE_RES)
-                            {
-                                const float gw[4] = {gnWv[fj].x, gnWv[fj].y, gnWv[fj].z, gnWv[fj].w};
-                                const float gb[4] = {gnBv[fj].x, gnBv[fj].y, gnBv[fj].z, gnBv[fj].w};
-                                const float hw[4] = {gnWv[fj + 1].x, gnWv[fj + 1].y, gnWv[fj + 1].z, gnWv[fj + 1].w};
-                                const float hb[4] = {gnBv[fj + 1].x, gnBv[fj + 1].y, gnBv[fj + 1].z, gnBv[fj + 1].w};
-                                const float sv[4] = {scalev[fj].x, scalev[fj].y, scalev[fj].z, scalev[fj].w};
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                {
-                                    const float a = (av[r] - mean) * sc * gw[r] + gb[r];
-                                    const float g = (gv[r] - mean) * sc * hw[r] + hb[r];
-                                    ov[r] = rv[r] + sv[r] * (a * dsigmoid(g));
-                                }
-                            }
-                            else
-                            {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    ov[r] = av[r] * dsigmoid(gv[r]) + rv[r];
-                            }
-                            *reinterpret_cast<float4 *>(p.Y + em * p.ldy + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                        }
-                    }
-                }
-            }
-            else // EPI_TRCONV
-            {
-                i64 offs[NF];
-                float4 resv[NF];
-#pragma unroll
-                for (int fj = 0; fj < NF; ++fj)
-                {
-                    const int n = fj * 16 + 4 * h;
-                    const int jj = 4 * p0 + trR[fj] - 2;
-                    offs[fj] = (eOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)b * p.yBS + ((i64)p1 * p.Lout + jj) * p.ldy + trC[fj] : -1;
-                    resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                if (p.res)
-                {
-#pragma unroll
-                    for (int fj = 0; fj < NF; ++fj)
-                        if (offs[fj] >= 0)
-                            resv[fj] = *reinterpret_cast<const float4 *>(p.res + offs[fj]);
-                }
-#pragma unroll
-                for (int fj = 0; fj < NF; ++fj)
-                    if (offs[fj] >= 0)
-                    {
-                        float4 v = make_float4(acc[fj][0] + biasv[fj].x, acc[fj][1] + biasv[fj].y, acc[fj][2] + biasv[fj].z,
-                                               acc[fj][3] + biasv[fj].w);
                         if (p.act)
                             v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
                         v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
-                        *reinterpret_cast<float4 *>(p.Y + offs[fj]) = v;
+                        *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
                     }
+                    s += (v.x + v.y) + (v.z + v.w);
+                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            }
+            if (p.rowstat)
+            {
+                s += __shfl_xor(s, 16);
+                ss += __shfl_xor(ss, 16);
+                s += __shfl_xor(s, 32);
+                ss += __shfl_xor(ss, 32);
+                if (h == 0 && eOk)
+                    *reinterpret_cast<float2 *>(p.rowstat + em * 2) = make_float2(s, ss); // NB == 1
             }
         }
+        else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+        {
+            if constexpr (NF % 2 == 0)
+            {
+                const float mean = st.eMean, sc = st.eSc;
+#pragma unroll
+                for (int fj = 0; fj < NF; fj += 2)
+                {
+                    const int c = (fj >> 1) * 16 + 4 * h;
+                    if (eOk && c < C2)
+                    {
+                        const float4 ba = CST_LDS ? cst[0][fj][h] : biasv[CST_LDS ? 0 : fj];
+                        const float4 bg = CST_LDS ? cst[0][fj + 1][h] : biasv[CST_LDS ? 0 : fj + 1];
+                        float av[4] = {acc[fj][0] + ba.x, acc[fj][1] + ba.y, acc[fj][2] + ba.z, acc[fj][3] + ba.w};
+                        float gv[4] = {acc[fj + 1][0] + bg.x, acc[fj + 1][1] + bg.y, acc[fj + 1][2] + bg.z, acc[fj + 1][3] + bg.w};
+                        const float4 r4 = st.resv[fj >> 1];
+                        const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                        float ov[4];
+                        if (EPI == EPI_GN_GLU_SCALE_RES)
+                        {
+                            const float4 gw4 = cst[CST_LDS ? 1 : 0][fj][h], gb4 = cst[CST_LDS ? 2 : 0][fj][h];
+                            const float4 hw4 = cst[CST_LDS ? 1 : 0][fj + 1][h], hb4 = cst[CST_LDS ? 2 : 0][fj + 1][h];
+                            const float4 sv4 = cst[CST_LDS ? 3 : 0][fj][h];
+                            const float gw[4] = {gw4.x, gw4.y, gw4.z, gw4.w};
+                            const float gb[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+                            const float hw[4] = {hw4.x, hw4.y, hw4.z, hw4.w};
+                            const float hb[4] = {hb4.x, hb4.y, hb4.z, hb4.w};
+                            const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                            {
+                                const float a = (av[r] - mean) * sc * gw[r] + gb[r];
+                                const float g = (gv[r] - mean) * sc * hw[r] + hb[r];
+                                ov[r] = rv[r] + sv[r] * (a * dsigmoid(g));
+                            }
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                ov[r] = av[r] * dsigmoid(gv[r]) + p.tableScale * rv[r];
+                        }
+                        *reinterpret_cast<float4 *>(p.Y + em * p.ldy + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                    }
+                }
+            }
+        }
+        else // EPI_TRCONV
+        {
+            i64 offs[NF];
+            float4 resv[NF];
+#pragma unroll
+            for (int fj = 0; fj < NF; ++fj)
+            {
+                const int n = fj * 16 + 4 * h;
+                const int jj = 4 * p0 + trR[fj] - 2;
+                offs[fj] = (eOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)b * p.yBS + ((i64)p1 * p.Lout + jj) * p.ldy + trC[fj] : -1;
+                resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (p.res)
+            {
+#pragma unroll
+                for (int fj = 0; fj < NF; ++fj)
+                    if (offs[fj] >= 0)
+                        resv[fj] = *reinterpret_cast<const float4 *>(p.res + offs[fj]);
+            }
+#pragma unroll
+            for (int fj = 0; fj < NF; ++fj)
+                if (offs[fj] >= 0)
+                {
+                    const float4 bi = biasv[CST_LDS ? 0 : fj];
+                    float4 v = make_float4(acc[fj][0] + bi.x, acc[fj][1] + bi.y, acc[fj][2] + bi.z, acc[fj][3] + bi.w);
+                    if (p.act)
+                        v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
+                    v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
+                    *reinterpret_cast<float4 *>(p.Y + offs[fj]) = v;
+                }
+        }
+    };
+
+    Stage cur, nxt;
+    fetch(gwave, cur);
+    for (int frag = gwave; frag < nfrag; frag += nwaves)
+    {
+        fetch(frag + nwaves, nxt); // beyond the end: every load goes to the zero page
+        compute(cur);
+        cur = nxt;
     }
 }
 
