@@ -45,6 +45,24 @@ PEAK_TFLOPS_FP32_MFMA = 157.3
 MODEL_FLOPS_4S = 340.2e9  # algorithmic FLOPs per segment (SURVEY.md §8d / BASELINE.md §3)
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes
+    (profiles/rNN_traffic.json, written by tools/traffic_json.py from separate FETCH_SIZE and
+    WRITE_SIZE passes over `bench.py --batch 12`; gfx950 corrections applied there). The counters
+    cannot be collected from inside this process, so the newest committed pass is quoted."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d["classes"][kernel_class]["traffic_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "12")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +155,18 @@ def main():
 
     finite = bool(torch.isfinite(out).all().item())
 
+    # BASELINE.json configs[1] read literally: ONE segment per call (latency), device resident
+    single_ms = None
+    if rank == 0 and world == 1 and not args.no_single:
+        for _ in range(2):
+            ctx.segment_device(mix.data_ptr(), out.data_ptr(), 1)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ctx.segment_device(mix.data_ptr(), out.data_ptr(), 1)
+        ctx.synchronize()
+        single_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         prof = ctx.profile(B, 3)
@@ -150,9 +181,11 @@ def main():
         kname, (ms, fl, by, cnt) = dom
         tot_ms = sum(v[0] for v in by_kernel.values())
         achieved = fl / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(kname) if B == 12 else (None, None)
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "algorithmic_flops_per_launch": fl / cnt, "algorithmic_bytes_per_launch": by / cnt,
             "kernel_share_of_device_time": round(ms / tot_ms, 3),
@@ -197,6 +230,8 @@ def main():
                                    + (" + RCCL gather to root" if world > 1 else ""),
                        "segments_per_gpu_per_step": B, "segment_samples": SEG, "audio_seconds_per_segment": SEG_SECONDS,
                        "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
+                       "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
+                       "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        "parallelism": f"segment-sharded x{world}"},
         }
         if roofline:

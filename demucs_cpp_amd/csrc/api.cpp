@@ -53,7 +53,11 @@ struct dmx_ctx
     std::map<int, std::unique_ptr<Plan>> plans;
     float *dA = nullptr;
     i64 arenaFloats = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // main / freq branch; every API call is ordered on this stream
+    hipStream_t stream2 = nullptr; // time branch (forked from and joined back into `stream` inside run_plan)
+    bool twoStreams = true;        // DMX_STREAMS=1 runs the plan on one stream (A/B, debugging)
+    std::vector<hipEvent_t> events; // one per op index (created on first use), + fork / join
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     int lastBatch = 0;
     // track-level scratch
     double *dPartials = nullptr;
@@ -169,6 +173,13 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float)));
     HIPCHK(hipMemcpy(c->dA, p->constants.data(), p->constants.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    {
+        const char *e = getenv("DMX_STREAMS");
+        c->twoStreams = !(e && atoi(e) == 1);
+    }
     HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
     HIPCHK(hipMalloc((void **)&c->dSegIdx, sizeof(int) * 4096));
     *out = c.release();
@@ -185,6 +196,18 @@ extern "C" void dmx_ctx_free(dmx_ctx *c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    if (c->stream2)
+    {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    for (hipEvent_t e : c->events)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->evFork)
+        (void)hipEventDestroy(c->evFork);
+    if (c->evJoin)
+        (void)hipEventDestroy(c->evJoin);
     if (c->dA)
         (void)hipFree(c->dA);
     if (c->dPartials)
@@ -292,8 +315,40 @@ static int run_plan(dmx_ctx *c, int batch)
     Plan *p = get_plan(c, batch);
     if (p->arenaFloats > c->arenaFloats)
         return fail(DMX_ERR_ARG, "internal: plan for batch %d exceeds the arena", batch);
-    for (const Op &op : p->ops)
-        launch_op(c, op, c->stream, p->zeroOff);
+    if (!c->twoStreams)
+    {
+        for (const Op &op : p->ops)
+            launch_op(c, op, c->stream, p->zeroOff);
+    }
+    else
+    {
+        // freq branch on `stream`, time branch on `stream2`, joined by the waits plan.cpp derived from
+        // the ops' arena ranges (Op::waitOp / Op::signals); fork and join bracket the whole plan so
+        // that callers only ever need to order themselves against `stream`.
+        const size_t n = p->ops.size();
+        if (c->events.size() < n)
+            c->events.resize(n, nullptr);
+        HIPCHK(hipEventRecord(c->evFork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+        for (size_t i = 0; i < n; ++i)
+        {
+            const Op &op = p->ops[i];
+            if (op.kind == OP_TAP)
+                continue;
+            hipStream_t s = op.stream ? c->stream2 : c->stream;
+            if (op.waitOp >= 0)
+                HIPCHK(hipStreamWaitEvent(s, c->events[(size_t)op.waitOp], 0));
+            launch_op(c, op, s, p->zeroOff);
+            if (op.signals)
+            {
+                if (!c->events[i])
+                    HIPCHK(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
+                HIPCHK(hipEventRecord(c->events[i], s));
+            }
+        }
+        HIPCHK(hipEventRecord(c->evJoin, c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+    }
     c->lastBatch = batch;
     HIPCHK(hipGetLastError());
     return DMX_OK;

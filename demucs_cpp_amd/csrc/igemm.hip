@@ -31,6 +31,10 @@
 #define DMX_PIN_LOADS 0
 #endif
 
+#ifndef DMX_CFG2_KS
+#define DMX_CFG2_KS 2
+#endif
+
 namespace dmx
 {
 
@@ -543,11 +547,11 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(7, 2, 2, 2, 4, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, 2, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 2: 128x96
-        DMX_CASE(2, 4, 1, 2, 6, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(2, 4, 1, 2, 6, 1, PRO_NONE, EPI_GLU)
-        DMX_CASE(2, 4, 1, 2, 6, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(2, 4, 1, 2, 6, 1, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_CASE(2, 4, 1, 2, 6, 1, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_GLU)
+        DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 3: 128x48
         DMX_CASE(3, 4, 1, 2, 3, 1, PRO_NONE, EPI_LINEAR)
         DMX_CASE(3, 4, 1, 2, 3, 1, PRO_NONE, EPI_TRCONV)

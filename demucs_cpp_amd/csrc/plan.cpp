@@ -675,6 +675,146 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
         o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad};
         pl.ops.push_back(o2);
     }
+    compute_deps(pl);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-stream dependencies. The two branches of the model (/root/reference/src/model_inference.cpp
+// runs them one after the other on one thread) only meet at the STFT output, in the cross-attention
+// layers and in the final sum, so the engine runs them on two HIP streams. Instead of hand-placing
+// the joins, every op declares the arena ranges it touches and the joins are derived: op i must wait
+// for the latest earlier op j of the other stream with a RAW, WAR or WAW overlap.
+void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
+{
+    rd.clear();
+    wr.clear();
+    auto R = [&](i64 lo, i64 n) {
+        if (lo >= 0 && n > 0)
+            rd.push_back(Range{lo, lo + n});
+    };
+    auto Wr = [&](i64 lo, i64 n) {
+        if (lo >= 0 && n > 0)
+            wr.push_back(Range{lo, lo + n});
+    };
+    switch (op.kind)
+    {
+    case OP_IGEMM:
+    {
+        const IGemm &g = op.g;
+        const i64 M = (i64)g.B * g.P1 * g.P0;
+        R(g.x, (i64)(g.B - 1) * g.xBatchStride + (i64)g.L1 * g.L0 * g.Cin);
+        if (g.pro != PRO_NONE)
+            R(g.proStats, (i64)g.B * std::max(g.G0, 1) * 4);
+        i64 yext;
+        if (g.epi == EPI_TRCONV)
+            yext = (i64)(g.B - 1) * g.yBatchStride + (i64)g.P1 * g.Lout * g.ldy;
+        else
+            yext = (M - 1) * g.ldy + g.N;
+        if (g.epi != EPI_STATS_ONLY)
+            Wr(g.y, yext);
+        if (g.res >= 0)
+            R(g.res, yext);
+        if (g.epi == EPI_GN_GLU_SCALE_RES)
+            R(g.epiStats, (i64)g.B * std::max(g.G0, 1) * 4);
+        if (g.rowstat >= 0)
+            Wr(g.rowstat, M * std::max(g.NB, 1) * 2);
+        break;
+    }
+    case OP_STATS_REDUCE:
+    {
+        const StatsReduce &s = op.sr;
+        R(s.rowstat, (i64)s.B * s.R * s.NB * 2);
+        Wr(s.out, (i64)s.B * std::max(s.G0, 1) * 4);
+        if (s.scratch >= 0)
+        {
+            R(s.scratch, (i64)s.B * s.nchunk * 4);
+            Wr(s.scratch, (i64)s.B * s.nchunk * 4);
+        }
+        break;
+    }
+    case OP_STFT:
+    {
+        const Stft &s = op.stft;
+        R(s.mix, (i64)s.B * s.seg * 2);
+        Wr(s.x, (i64)s.B * s.T * 2048 * 4);
+        Wr(s.rowstat, (i64)s.B * s.T * 2);
+        Wr(s.rowstatT, (i64)s.B * s.T * 2);
+        break;
+    }
+    case OP_LAYERNORM:
+        R(op.ln.x, (i64)op.ln.rows * op.ln.D);
+        Wr(op.ln.y, (i64)op.ln.rows * op.ln.D);
+        break;
+    case OP_GN_APPLY:
+    {
+        const GnApply &g = op.gn;
+        const i64 n = (i64)g.B * g.rows * g.C;
+        R(g.x, n);
+        R(g.res, n);
+        R(g.stats, (i64)g.B * 4);
+        Wr(g.y, n);
+        break;
+    }
+    case OP_ATTENTION:
+    {
+        const Attention &t = op.at;
+        R(t.q, (i64)(t.B - 1) * t.qBatch + (i64)(t.Tq - 1) * t.ldq + (i64)t.H * t.hs);
+        R(t.k, (i64)(t.B - 1) * t.kBatch + (i64)(t.Tk - 1) * t.ldk + (i64)t.H * t.hs);
+        R(t.v, (i64)(t.B - 1) * t.vBatch + (i64)(t.Tk - 1) * t.ldv + (i64)t.H * t.hs);
+        Wr(t.o, (i64)(t.B - 1) * t.oBatch + (i64)(t.Tq - 1) * t.ldo + (i64)t.H * t.hs);
+        break;
+    }
+    case OP_ISTFT:
+        R(op.istft.x, (i64)op.istft.B * op.istft.T * 2048 * 4 * op.istft.S);
+        R(op.istft.stats, (i64)op.istft.B * 4);
+        Wr(op.istft.frames, (i64)op.istft.B * op.istft.S * 2 * op.istft.T * 4096);
+        break;
+    case OP_OLA:
+        R(op.ola.frames, (i64)op.ola.B * op.ola.S * 2 * op.ola.T * 4096);
+        R(op.ola.xt, (i64)op.ola.B * op.ola.seg * 2 * op.ola.S);
+        R(op.ola.statsT, (i64)op.ola.B * 4);
+        Wr(op.ola.out, (i64)op.ola.B * op.ola.S * 2 * op.ola.seg);
+        break;
+    default:
+        break;
+    }
+}
+
+void compute_deps(Plan &pl)
+{
+    const int n = (int)pl.ops.size();
+    std::vector<std::vector<Range>> rd(n), wr(n);
+    for (int i = 0; i < n; ++i)
+        op_access(pl.ops[i], rd[i], wr[i]);
+    auto overlap = [](const std::vector<Range> &a, const std::vector<Range> &b) {
+        for (const Range &x : a)
+            for (const Range &y : b)
+                if (x.lo < y.hi && y.lo < x.hi)
+                    return true;
+        return false;
+    };
+    int waited[2] = {-1, -1}; // per stream: the latest op of the other stream it has already joined
+    for (int i = 0; i < n; ++i)
+    {
+        Op &op = pl.ops[i];
+        op.waitOp = -1;
+        if (op.kind == OP_TAP)
+            continue;
+        const int s = op.stream ? 1 : 0;
+        for (int j = i - 1; j > waited[s]; --j)
+        {
+            const Op &o = pl.ops[j];
+            if (o.kind == OP_TAP || (o.stream ? 1 : 0) == s)
+                continue;
+            if (overlap(wr[j], rd[i]) || overlap(wr[j], wr[i]) || overlap(rd[j], wr[i]))
+            {
+                op.waitOp = j;
+                waited[s] = j;
+                pl.ops[j].signals = true;
+                break;
+            }
+        }
+    }
 }
 
 } // namespace dmx

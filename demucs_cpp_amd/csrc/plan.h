@@ -182,7 +182,10 @@ struct Tap
 struct Op
 {
     int kind;
-    int stream; // 0 = freq branch / main, 1 = time branch (engine may run them concurrently)
+    int stream; // 0 = freq branch / main, 1 = time branch (the engine runs them on two HIP streams)
+    int waitOp = -1;     // index of the latest op of the OTHER stream this op has a data hazard with
+                         // (RAW, WAR or WAW on the arena), -1 if none or already implied (compute_deps)
+    bool signals = false; // some later op of the other stream waits on this op
     std::string name;
     IGemm g;
     StatsReduce sr;
@@ -254,5 +257,13 @@ struct Plan
 bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err);
 // plan.cpp
 void build_plan(const PackedModel &pm, i64 seg, int B, Plan &plan);
+// arena ranges [lo, hi) an op reads / writes (conservative hulls); constants and W space excluded
+struct Range
+{
+    i64 lo, hi;
+};
+void op_access(const Op &op, std::vector<Range> &reads, std::vector<Range> &writes);
+// fills Op::waitOp / Op::signals from the access ranges (called by build_plan)
+void compute_deps(Plan &plan);
 
 } // namespace dmx

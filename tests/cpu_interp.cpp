@@ -388,10 +388,54 @@ struct Interp
         }
     }
 
-    void run()
+    // order: 0 = plan order. 1 / 2 = the most skewed interleavings two concurrent streams may produce
+    // under the derived cross-stream waits (Op::waitOp): always advance stream (order-1) as far as its
+    // waits allow before the other stream takes ONE step. If the derived waits were missing a
+    // hazard, one of the two skews would reorder the conflicting ops and change the result.
+    std::vector<int> schedule(int order) const
     {
-        for (auto &op : pl.ops)
+        const int n = (int)pl.ops.size();
+        std::vector<int> seq;
+        if (order == 0)
         {
+            for (int i = 0; i < n; ++i)
+                seq.push_back(i);
+            return seq;
+        }
+        std::vector<int> q[2];
+        for (int i = 0; i < n; ++i)
+            q[pl.ops[i].stream ? 1 : 0].push_back(i);
+        size_t pos[2] = {0, 0};
+        std::vector<char> done(n, 0);
+        const int fav = order - 1;
+        auto ready = [&](int s) {
+            if (pos[s] >= q[s].size())
+                return false;
+            const int w = pl.ops[q[s][pos[s]]].waitOp;
+            return w < 0 || done[w];
+        };
+        auto step = [&](int s) {
+            const int i = q[s][pos[s]++];
+            done[i] = 1;
+            seq.push_back(i);
+        };
+        while (pos[0] < q[0].size() || pos[1] < q[1].size())
+        {
+            if (ready(fav))
+                step(fav);
+            else if (ready(1 - fav))
+                step(1 - fav);
+            else
+                return std::vector<int>(); // deadlock: cannot happen (waits only point backwards)
+        }
+        return seq;
+    }
+
+    void run(int order = 0)
+    {
+        for (int idx : schedule(order))
+        {
+            const Op &op = pl.ops[idx];
             switch (op.kind)
             {
             case OP_IGEMM: run_igemm(op.g); break;
@@ -431,6 +475,22 @@ extern "C"
     int interp_n_ops(void *h) { return (int)((Interp *)h)->pl.ops.size(); }
     double interp_arena_mb(void *h) { return (double)((Interp *)h)->pl.arenaFloats * 4 / 1e6; }
     // mix [B][seg][2] interleaved -> out [B][S][2][seg]
+    // number of cross-stream waits in the plan
+    int interp_n_waits(void *h)
+    {
+        int c = 0;
+        for (auto &op : ((Interp *)h)->pl.ops)
+            c += op.waitOp >= 0;
+        return c;
+    }
+    void interp_run_order(void *h, const float *mix, float *out, int order)
+    {
+        Interp *it = (Interp *)h;
+        const Plan &pl = it->pl;
+        std::memcpy(&it->A[(size_t)pl.mixOff], mix, sizeof(float) * (size_t)(pl.B * pl.geo.seg * 2));
+        it->run(order);
+        std::memcpy(out, &it->A[(size_t)pl.outOff], sizeof(float) * (size_t)((i64)pl.B * pl.S * 2 * pl.geo.seg));
+    }
     void interp_run(void *h, const float *mix, float *out)
     {
         Interp *it = (Interp *)h;

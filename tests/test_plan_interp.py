@@ -63,3 +63,27 @@ def test_plan_batch_equals_singles_and_oracle(interp, tmp_models):
         ref = m.segment(mixes[b])
         assert np.abs(both[b] - ref).max() / np.abs(ref).max() < 2e-5
     m.close()
+
+
+@pytest.mark.parametrize("ns", [4, 6])
+def test_two_stream_waits_cover_every_hazard(ns, interp, tmp_models):
+    """The engine runs the freq and time branches on two HIP streams joined only by the waits
+    plan.cpp derives from the ops' arena ranges. Executing the plan in the two most skewed
+    interleavings those waits permit must reproduce plan order bit for bit."""
+    interp.interp_run_order.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int]
+    interp.interp_n_waits.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(11)
+    seg = 6000
+    mix = (0.1 * rng.standard_normal((1, seg, 2))).astype(np.float32)
+    outs = []
+    for order in (0, 1, 2):
+        h = interp.interp_create(tmp_models[ns].encode(), seg, 1)
+        nw = interp.interp_n_waits(h)
+        out = np.zeros((1, ns, 2, seg), np.float32)
+        interp.interp_run_order(h, mix.ctypes.data, out.ctypes.data, order)
+        interp.interp_free(h)
+        outs.append(out)
+    assert 4 <= nw <= 64, nw  # joins exist (STFT fan-out, cross layers, final sum) and stay few
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
