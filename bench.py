@@ -104,54 +104,81 @@ def main():
     os.remove(mpath)
     ctx = dmx.Context(model, SEG, B)
 
+    # Everything device-side is ordered on ONE torch stream: the library enqueues on it
+    # (dmx_ctx_set_stream), torch ops run on it, RCCL collectives fork from / join into it. The host
+    # never blocks inside the timed region, so the gather of step i (RCCL, xGMI) and the root's
+    # overlap-add of step i-1 overlap the kernels of the following step on every rank.
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    torch.cuda.set_stream(stream)
+
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
     mix = (0.1 * torch.randn((B, SEG, 2), generator=gen)).cuda()  # interleaved stereo, resident in HBM
-    out = torch.zeros((B, S, 2, SEG), device="cuda")
+    outs = [torch.zeros((B, S, 2, SEG), device="cuda") for _ in range(2)]  # double buffered: step i -> slot i & 1
+    out = outs[0]
     nseg_total = world * B
     stride = int((1 - 0.25) * SEG)
     # the N*B segments of one step form a stretch of a track whose segment loop
     # (`for offset < len; offset += stride`) has exactly nseg_total iterations: len = nseg*stride
     n_track = nseg_total * stride - 22050  # shift offset 0: len = n + 22050
     d_stats = torch.tensor([0.0, 1.0, 0.0, 0.0], device="cuda")
-    gathered = None
+    allseg = [None, None]   # root: [world*B][S][2][SEG] per slot, rank-major; the gather lands in views of it
+    gathered = [None, None]
     track_out = None
     if rank == 0:
-        gathered = [torch.zeros_like(out) for _ in range(world)]
-        track_out = torch.zeros((S, 2, n_track), device="cuda")
-
-    torch.cuda.synchronize()  # inputs produced on torch's stream are complete before the library's stream reads them
-
-    def step():
-        ctx.segment_device(mix.data_ptr(), out.data_ptr(), B)
-        ctx.synchronize()  # the library runs on its own stream; hand over to torch's stream / RCCL
         if world > 1:
-            dist.gather(out, gathered if rank == 0 else None, dst=0)
-            if rank == 0:
-                allseg = torch.cat(gathered, dim=0)
+            allseg = [torch.zeros((world * B, S, 2, SEG), device="cuda") for _ in range(2)]
+            gathered = [list(a.chunk(world, dim=0)) for a in allseg]
         else:
-            allseg = out
+            allseg = outs
+        track_out = torch.zeros((S, 2, n_track), device="cuda")
+    works = [None, None]
+    state = {"pending": None}
+    torch.cuda.synchronize()
+
+    def finish(slot):
+        """root: triangle-weighted overlap-add of the step held in `slot` (after its gather landed)"""
+        if world > 1:
+            works[slot].wait()  # stream-level: `stream` waits for the RCCL gather
+        ctx.track_overlap_add_device(allseg[slot].data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), track_out.data_ptr())
+
+    def step(i):
+        slot = i & 1
+        if world > 1 and works[slot] is not None:
+            works[slot].wait()  # the gather that last read outs[slot] (step i-2) is complete before it is overwritten
+        ctx.segment_device(mix.data_ptr(), outs[slot].data_ptr(), B)
+        if world > 1:
+            works[slot] = dist.gather(outs[slot], gathered[slot] if rank == 0 else None, dst=0, async_op=True)
         if rank == 0:
-            torch.cuda.current_stream().synchronize()
-            ctx.track_overlap_add_device(allseg.data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), track_out.data_ptr())
-            ctx.synchronize()
+            if state["pending"] is not None:
+                finish(state["pending"])  # previous step's overlap-add, behind this step's kernels
+            state["pending"] = slot
+
+    def flush():
+        if rank == 0 and state["pending"] is not None:
+            finish(state["pending"])
+        state["pending"] = None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    flush()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    flush()  # the timed region contains exactly K segment batches, K gathers, K overlap-adds
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    out = outs[(args.steps - 1) & 1] if args.steps > 0 else outs[0]
 
     finite = bool(torch.isfinite(out).all().item())
 

@@ -25,7 +25,7 @@ MAX_SHIFT = 22050
 EXPORTS = [
     "dmx_last_error", "dmx_device_count", "dmx_model_load", "dmx_model_free", "dmx_model_n_sources",
     "dmx_model_n_tensors", "dmx_model_device", "dmx_ctx_create", "dmx_ctx_free", "dmx_ctx_segment_samples",
-    "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_segment_infer",
+    "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_ctx_set_stream", "dmx_segment_infer",
     "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
     "dmx_debug_profile", "dmx_debug_igemm_timing",
@@ -70,6 +70,7 @@ def lib():
         L.dmx_ctx_arena_bytes.argtypes = [vp]
         L.dmx_ctx_arena_bytes.restype = i64
         L.dmx_ctx_synchronize.argtypes = [vp]
+        L.dmx_ctx_set_stream.argtypes = [vp, vp]
         L.dmx_segment_infer.argtypes = [vp, fp, fp, ci]
         L.dmx_segment_infer_device.argtypes = [vp, fp, fp, ci]
         L.dmx_track_infer.argtypes = [vp, fp, i64, ci, fp, ci, vp, vp]
@@ -142,6 +143,11 @@ class Context:
 
     def synchronize(self):
         _chk(lib().dmx_ctx_synchronize(self.h))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        """Order the context's device work on a caller-owned hipStream_t (raw handle, e.g.
+        torch.cuda.Stream().cuda_stream); None returns to the context's own stream."""
+        _chk(lib().dmx_ctx_set_stream(self.h, ctypes.c_void_p(hip_stream) if hip_stream else None))
 
     # ---- host-pointer API
     def segment(self, mix: np.ndarray) -> np.ndarray:

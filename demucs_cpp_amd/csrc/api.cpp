@@ -54,6 +54,7 @@ struct dmx_ctx
     float *dA = nullptr;
     i64 arenaFloats = 0;
     hipStream_t stream = nullptr;  // main / freq branch; every API call is ordered on this stream
+    hipStream_t ownStream = nullptr; // the stream created with the context (`stream` may be a caller's)
     hipStream_t stream2 = nullptr; // time branch (forked from and joined back into `stream` inside run_plan)
     bool twoStreams = true;        // DMX_STREAMS=1 runs the plan on one stream (A/B, debugging)
     std::vector<hipEvent_t> events; // one per op index (created on first use), + fork / join
@@ -172,7 +173,8 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float)));
     HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float)));
     HIPCHK(hipMemcpy(c->dA, p->constants.data(), p->constants.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+    c->stream = c->ownStream;
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
@@ -192,9 +194,11 @@ extern "C" void dmx_ctx_free(dmx_ctx *c)
         return;
     (void)hipSetDevice(c->m->device);
     if (c->stream)
-    {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+    if (c->ownStream)
+    {
+        (void)hipStreamSynchronize(c->ownStream);
+        (void)hipStreamDestroy(c->ownStream);
     }
     if (c->stream2)
     {
@@ -225,6 +229,17 @@ extern "C" int dmx_ctx_synchronize(dmx_ctx *c)
         return fail(DMX_ERR_ARG, "null ctx");
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
+{
+    if (!c)
+        return fail(DMX_ERR_ARG, "dmx_ctx_set_stream: null context");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     return DMX_OK;
 }
 

@@ -75,6 +75,13 @@ extern "C"
     int dmx_ctx_max_batch(const dmx_ctx *c);
     int64_t dmx_ctx_arena_bytes(const dmx_ctx *c);
     int dmx_ctx_synchronize(dmx_ctx *c);
+    /* Order the context's device work on a caller-owned HIP stream (a hipStream_t passed as void*,
+     * e.g. the stream a framework issues its own kernels and RCCL collectives on): every *_device
+     * entry point then enqueues behind / ahead of the caller's work on that stream and no host
+     * synchronisation is needed around the calls. NULL returns to the context's own stream.
+     * The context synchronises its current stream before switching. (No reference counterpart:
+     * the Eigen path is synchronous host code.) */
+    int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream);
 
     /* Replaces demucscpp::model_inference (src/model.hpp:662-666,
      * src/model_inference.cpp:48): one full segment, host pointers.

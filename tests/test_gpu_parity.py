@@ -97,6 +97,32 @@ def test_batch_equals_singles_bitwise_and_layouts(dmx, tmp_models):
     ctx.close(); m.close()
 
 
+def test_caller_stream_ordering_without_host_sync(dmx, tmp_models):
+    """dmx_ctx_set_stream: the library's work (both of its internal streams) is ordered on the
+    caller's stream, so torch producers / consumers on that stream need no host synchronisation."""
+    import torch
+    seg, B = 6000, 2
+    rng = np.random.default_rng(12)
+    mixes = (0.1 * rng.standard_normal((B, 2, seg))).astype(np.float32)
+    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, seg, B)
+    ref = np.stack([ctx.segment(mixes[b]) for b in range(B)])
+    s = torch.cuda.Stream()
+    ctx.set_stream(s.cuda_stream)
+    host = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).pin_memory()
+    with torch.cuda.stream(s):
+        for _ in range(3):  # back to back: reuse of the arena and of the I/O tensors is stream ordered too
+            d_mix = host.to("cuda", non_blocking=True) * 1.0   # produced on s right before the call
+            d_out = torch.empty((B, 4, 2, seg), device="cuda")
+            ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+            y = d_out + 0.0                                      # consumed on s right after the call
+            d_mix.zero_()                                        # and the input clobbered (after the library read it)
+    s.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ref)
+    ctx.set_stream(None)
+    assert np.array_equal(ctx.segment(mixes[0]), ref[0])
+    ctx.close(); m.close()
+
+
 def test_full_size_segment_vs_oracle(dmx, tmp_models, oracle_threads):
     # BASELINE.json configs[0] vs configs[1]: the full 7.8 s segment (2 x 343980)
     rng = np.random.default_rng(0)
