@@ -123,16 +123,18 @@ def test_caller_stream_ordering_without_host_sync(dmx, tmp_models):
     ctx.close(); m.close()
 
 
-def test_full_size_segment_vs_oracle(dmx, tmp_models, oracle_threads):
-    # BASELINE.json configs[0] vs configs[1]: the full 7.8 s segment (2 x 343980)
-    rng = np.random.default_rng(0)
+@pytest.mark.parametrize("ns", [4, 6])
+def test_full_size_segment_vs_oracle(ns, dmx, tmp_models, oracle_threads):
+    # BASELINE.json configs[0] vs configs[1] (4 sources) and the configs[3] model (6 sources):
+    # the full 7.8 s segment (2 x 343980), every tapped layer and the output
+    rng = np.random.default_rng(ns)
     mix = (0.1 * rng.standard_normal((2, SEG_FULL))).astype(np.float32)
-    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 1); om = orc.OracleModel(tmp_models[4])
+    m = dmx.Model(tmp_models[ns]); ctx = dmx.Context(m, 0, 1); om = orc.OracleModel(tmp_models[ns])
     assert ctx.seg == SEG_FULL
     errs, out, ref = pu.compare_segment(ctx, om, mix)
     bad = {k: v for k, v in errs.items() if not (v < TOL)}
     assert not bad, bad
-    for s in range(4):
+    for s in range(ns):
         assert sdr_db(ref[s], out[s]) > 60.0
     ctx.close(); m.close(); om.close()
 
@@ -235,3 +237,74 @@ def test_cli_drop_in(dmx, tmp_models, golden_dir, tmp_path):
     assert subprocess.run([exe], capture_output=True).returncode == 1
     assert subprocess.run([exe, "/nonexistent.bin", wav, str(out_dir)], capture_output=True).returncode == 1
     ctx.close(); m.close()
+
+
+def test_cli_mt_and_ft_drop_in(dmx, tmp_models, golden_dir, tmp_path):
+    """The *_mt and fine-tuned CLIs (SURVEY.md §8f rank 1, §8d configs[4]): argv contracts of
+    /root/reference/cli-apps/demucs_mt.cpp:108-116, demucs_ft.cpp:109-114, demucs_ft_mt.cpp:108-116;
+    <num threads> = number of coarse 0.75 s-overlap chunks (threaded_inference.hpp), recombined
+    exactly as oracle/threaded_split.py restates it; ft: stem i from model i."""
+    import shutil
+    import subprocess
+    import sys
+    from wavio import read_wav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    from threaded_split import threaded_split
+    exe_mt = os.path.join(root, "cli", "demucs_mt.cpp.main")
+    exe_ft = os.path.join(root, "cli", "demucs_ft.cpp.main")
+    exe_ftmt = os.path.join(root, "cli", "demucs_ft_mt.cpp.main")
+    for e in (exe_mt, exe_ft, exe_ftmt):
+        if not os.path.exists(e):
+            pytest.skip("CLI not built")
+    from wavio import write_wav_f32
+    # 4 s of noise: chunks of 2 s > the 1.5 s of ramps, the regime the reference's driver is defined for
+    audio = (0.1 * np.random.default_rng(21).standard_normal((2, 4 * 44100))).astype(np.float32)
+    wav = str(tmp_path / "noise4s.wav")
+    write_wav_f32(wav, audio)
+    assert np.array_equal(read_wav(wav)[1], audio)
+    env = dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2")
+    names = ["drums", "bass", "other", "vocals"]
+
+    # ---- demucs_mt: 2 chunks
+    out_dir = tmp_path / "mt"
+    r = subprocess.run([exe_mt, tmp_models[4], wav, str(out_dir), "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "[THREAD 1]" in r.stdout
+    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 2)
+    ref = threaded_split(audio, 2, 4, lambda i, chunk: ctx.track(chunk, 1337))
+    for i, name in enumerate(names):
+        rate, stem = read_wav(str(out_dir / f"target_{i}_{name}.wav"))
+        assert rate == 44100 and stem.shape == audio.shape
+        assert np.abs(stem - ref[i]).max() <= 2e-6 * max(1.0, np.abs(ref[i]).max())
+    assert subprocess.run([exe_mt, tmp_models[4], wav, str(out_dir)], capture_output=True).returncode == 1  # 4 args required
+    ctx.close(); m.close()
+
+    # ---- fine-tuned bag: four 4-source files found by substring, stem i from model i
+    from demucs_cpp_amd.weights import write_synthetic_model
+    bag = tmp_path / "bag"
+    bag.mkdir()
+    paths = []
+    for i, name in enumerate(names):
+        pth = str(bag / f"ggml-model-htdemucs_ft_{name}-4s-f16.bin")
+        write_synthetic_model(pth, 4, 20 + i)
+        paths.append(pth)
+    out_ft = tmp_path / "ft"
+    r = subprocess.run([exe_ft, str(bag), wav, str(out_ft)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out_ftmt = tmp_path / "ftmt"
+    r2 = subprocess.run([exe_ftmt, str(bag), wav, str(out_ftmt), "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    for i, name in enumerate(names):
+        mi = dmx.Model(paths[i]); ci = dmx.Context(mi, 0, 2)
+        want = ci.track(audio, 1337)[i]
+        _, stem = read_wav(str(out_ft / f"target_{i}_{name}.wav"))
+        assert np.array_equal(stem, want)
+        want_mt = threaded_split(audio, 1, 4, lambda k, chunk: ci.track(chunk, 1337))[i]
+        _, stem_mt = read_wav(str(out_ftmt / f"target_{i}_{name}.wav"))
+        assert np.abs(stem_mt - want_mt).max() <= 2e-6 * max(1.0, np.abs(want_mt).max())
+        ci.close(); mi.close()
+    # a directory without the four models is an error (demucs_ft.cpp:178-184)
+    shutil.rmtree(bag)
+    bag.mkdir()
+    assert subprocess.run([exe_ft, str(bag), wav, str(out_ft)], capture_output=True).returncode == 1

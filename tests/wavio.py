@@ -23,3 +23,17 @@ def read_wav(path):
     else:
         raise ValueError("unsupported wav")
     return rate, a.reshape(-1, nch).T.copy()
+
+
+def write_wav_f32(path, audio, rate=44100):
+    """audio (2, n) float32 -> stereo IEEE-float WAV (the format the CLIs write)."""
+    import struct
+
+    import numpy as np
+
+    audio = np.asarray(audio, np.float32)
+    data = np.ascontiguousarray(audio.T).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 2, rate, rate * 8, 8, 32))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
