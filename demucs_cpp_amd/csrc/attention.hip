@@ -21,6 +21,7 @@
 //   V image  [key][HS + 4] floats (row padded by 4) -> V^T A-fragment = 4 ds_read_b32 with lanes on
 //            consecutive dims; the 4-float pad puts keys 4h and 4h+4 on disjoint bank halves.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace dmx
 {
@@ -41,8 +42,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, h4 = lane >> 4;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+    // workgroup -> (query tile, batch*head). Workgroup w runs on XCD w % 8: with the XCD-aware map every
+    // query tile of one (batch, head) lands on the same XCD, so its K and V (2 x Tk x d_h x 4 B, 1.4 MB)
+    // are fetched once and re-read from that XCD's L2 instead of once per XCD.
+    unsigned qt, bh;
+    if (p.xcdMap)
+    {
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned g = j / p.nQt;
+        qt = j - g * p.nQt;
+        bh = g * 8u + xcd;
+        if (bh >= (unsigned)(p.B * p.H))
+            return;
+    }
+    else
+    {
+        bh = blockIdx.x / p.nQt;
+        qt = blockIdx.x - bh * p.nQt;
+    }
+    const int b = (int)(bh / (unsigned)p.H), head = (int)(bh - (unsigned)b * (unsigned)p.H);
+    const int q0 = (int)qt * (64 * QF) + wave * (16 * QF);
     const float *Q = p.q + (i64)b * p.qB + head * HS;
     const float *K = p.k + (i64)b * p.kB + head * HS;
     const float *V = p.v + (i64)b * p.vB + head * HS;
@@ -220,17 +239,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
     }
 }
 
-void launch_attention(const AttnArgs &a, hipStream_t s)
+void launch_attention(const AttnArgs &a0, hipStream_t s)
 {
+    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
+    AttnArgs a = a0;
+    a.xcdMap = xcdMap;
     // 32 queries per wave (128 per workgroup) when that still leaves >= 2 rounds of workgroups per CU;
     // the key-tile order, hence every rounding, is the same for both shapes
     const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B;
     const bool big = wg128 >= 1024;
     if (a.hs != 64 && a.hs != 48)
         abort();
+    a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);
+    const unsigned nbh = (unsigned)(a.B * a.H);
+    const dim3 grid(xcdMap ? 8u * ((nbh + 7u) / 8u) * a.nQt : nbh * a.nQt);
     if (big)
     {
-        dim3 grid((a.Tq + 127) / 128, a.H, a.B);
         if (a.hs == 64)
             hipLaunchKernelGGL((attention_kernel<64, 2>), grid, dim3(256), 0, s, a);
         else
@@ -238,7 +262,6 @@ void launch_attention(const AttnArgs &a, hipStream_t s)
     }
     else
     {
-        dim3 grid((a.Tq + 63) / 64, a.H, a.B);
         if (a.hs == 64)
             hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(256), 0, s, a);
         else

@@ -64,8 +64,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const i64 m0 = (i64)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // workgroup -> tile. Workgroup b is dispatched to XCD b % 8 (observed; used for speed only). With the
+    // XCD-aware map all column tiles of a row tile run on the same XCD right after one another, so the
+    // A row block is fetched from HBM / Infinity Cache once and re-read from that XCD's 4 MB L2, and the
+    // 64 workgroups resident on an XCD form a (few row tiles) x (all column tiles) patch that shares both
+    // operands' k-slices. Row tiles are dealt round-robin to the XCDs (balanced to one tile).
+    unsigned tileM, tileN;
+    if (p.xcdMap)
+    {
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned mi = j / p.tilesN;
+        tileN = j - mi * p.tilesN;
+        tileM = mi * 8u + xcd;
+        if (tileM >= p.tilesM)
+            return; // whole workgroup, before any barrier
+    }
+    else
+    {
+        tileN = blockIdx.x / p.tilesM;
+        tileM = blockIdx.x - tileN * p.tilesM;
+    }
+    const i64 m0 = (i64)tileM * BM;
+    const int n0 = (int)tileN * BN;
 
     for (int r = tid; r < BM; r += 256)
     {
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #ifdef DMX_TIMING
     if (p.dbg && tid == 0)
     {
-        unsigned long long *d = p.dbg + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        unsigned long long *d = p.dbg + ((i64)tileN * p.tilesM + tileM) * 8;
         for (int i = 0; i < 5; ++i)
             d[i] = tacc[i];
         d[5] = (unsigned long long)nk;
@@ -504,7 +524,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                         s += rsum[r][w].x;
                         ss += rsum[r][w].y;
                     }
-                    float *dst = p.rowstat + (m * p.NB + blockIdx.y) * 2;
+                    float *dst = p.rowstat + (m * p.NB + tileN) * 2;
                     dst[0] = s;
                     dst[1] = ss;
                 }
@@ -513,12 +533,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 }
 
 template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
-static void launch_one(const GemmArgs &a, hipStream_t s)
+static void launch_one(const GemmArgs &a0, hipStream_t s)
 {
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
-    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
+    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1; // 0: plain row-major tiles (A/B)
+    GemmArgs a = a0;
+    a.tilesM = (unsigned)((a.M + BM - 1) / BM);
+    a.tilesN = (unsigned)((a.N + BN - 1) / BN);
+    a.xcdMap = xcdMap;
+    const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
     static const int padLds = getenv("DMX_IGEMM_PADLDS") ? atoi(getenv("DMX_IGEMM_PADLDS")) : 0; // experiment: limit residency
-    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI>), grid, dim3(256), padLds, s, a);
+    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI>), dim3(blocks), dim3(256), padLds, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the

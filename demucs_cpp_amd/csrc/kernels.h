@@ -31,6 +31,9 @@ struct GemmArgs
     i64 M;
     const float *zero; // >= 16 B of zeros, 16-byte aligned: target of out-of-range staging loads
     unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
+    // launch geometry (filled by launch_igemm): 1-D grid, workgroup id -> (row tile, column tile)
+    unsigned tilesM, tilesN;
+    int xcdMap; // 1: XCD-aware mapping (all column tiles of a row tile on ONE XCD, adjacent in dispatch order)
 };
 
 struct FastDiv // n / d for n < 2^31: magic == 0 ? n >> shift : umulhi(n, magic) >> shift
@@ -95,6 +98,8 @@ struct AttnArgs
     i64 qB, kB, vB, oB;
     int B, Tq, Tk, H, hs;
     float scale;
+    unsigned nQt; // query tiles per (batch, head) (filled by launch_attention)
+    int xcdMap;   // 1: all query tiles of one (batch, head) on ONE XCD (its K/V stay in that XCD's L2)
 };
 void launch_attention(const AttnArgs &a, hipStream_t s);
 
