@@ -28,6 +28,13 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f)
 {
     return f.magic ? (__umulhi(n, f.magic) >> f.shift) : (n >> f.shift);
 }
+// `ok ? *ptr : zero` as written selects between a global pointer and a private temporary and loads
+// through a FLAT pointer (plus a scratch slot); select the address against the zero page instead
+__device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *zero)
+{
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? ptr : zero);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float f4get(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 template <int NF, int S1, int SEG0, int PRO, int EPI>
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         {
 #pragma unroll
             for (int j = 0; j < NV4; ++j)
-                Bv[fj][s][j] = nOk ? *reinterpret_cast<const float4 *>(w + s * SEG0 + 16 * j + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                Bv[fj][s][j] = ld4z(w + s * SEG0 + 16 * j + 4 * h, nOk, p.zero);
 #pragma unroll
             for (int c = 0; c < RPL; ++c)
                 Br[fj][s][c] = nOk ? w[s * SEG0 + 16 * NV4 + RPL * h + c] : 0.f;
@@ -93,12 +100,11 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         for (int i = threadIdx.x; i < NF * 4; i += 256)
         {
             const int fj = i >> 2, hh = i & 3, n = fj * 16 + 4 * hh;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool ok = n < p.N;
-            cst[0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
-            cst[CST_LDS ? 1 : 0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.epiW + n) : z;
-            cst[CST_LDS ? 2 : 0][fj][hh] = ok ? *reinterpret_cast<const float4 *>(p.epiB + n) : z;
-            cst[CST_LDS ? 3 : 0][fj][hh] = (ok && (fj & 1) == 0) ? *reinterpret_cast<const float4 *>(p.scale + (fj >> 1) * 16 + 4 * hh) : z;
+            cst[0][fj][hh] = ld4z(p.bias + n, ok, p.zero);
+            cst[CST_LDS ? 1 : 0][fj][hh] = ld4z(p.epiW + n, ok, p.zero);
+            cst[CST_LDS ? 2 : 0][fj][hh] = ld4z(p.epiB + n, ok, p.zero);
+            cst[CST_LDS ? 3 : 0][fj][hh] = ld4z(p.scale + (fj >> 1) * 16 + 4 * hh, ok && (fj & 1) == 0, p.zero);
         }
         __syncthreads();
     }
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
     {
         const int n = fj * 16 + 4 * h; // N, Np, Cout are multiples of 4
         if (!CST_LDS)
-            biasv[fj] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            biasv[fj] = ld4z(p.bias + n, n < p.N, p.zero);
         trR[fj] = trC[fj] = 0;
         if (EPI == EPI_TRCONV)
         {
@@ -126,10 +132,10 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         int p0, p1;
         bool rowOk;
         float aMean, aScale, eMean, eSc;
-        float4 a4[S1][NV4A];
+        f32x4 a4[S1][NV4A]; // native vectors: whole-struct float4 copies (cur = nxt) would go through scratch
         float ar[S1][RPLA];
         unsigned ok4, okr; // validity bits [s * NV4 + j] / [s]
-        float4 resv[NRES];
+        f32x4 resv[NRES];
     };
     const int nfrag = (int)((p.M + 15) >> 4);
     const int C2 = p.N >> 1;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                 const int e = e0 + 16 * j + 4 * h;
                 const bool ok = ok1 && e >= 0 && e < rowLen;
                 st.ok4 |= (ok ? 1u : 0u) << (s * NV4 + j);
-                st.a4[s][j] = *reinterpret_cast<const float4 *>(ok ? rowp + e : p.zero);
+                st.a4[s][j] = *reinterpret_cast<const f32x4 *>(ok ? rowp + e : p.zero);
             }
             if (RPL > 0)
             {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         }
 #pragma unroll
         for (int r = 0; r < NRES; ++r)
-            st.resv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            st.resv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
         {
 #pragma unroll
@@ -199,9 +205,9 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                 if (rowOk && c < C2)
                 {
                     if (EPI == EPI_GN_GLU_SCALE_RES) // res may alias Y: rows are private to one lane, read before written
-                        st.resv[r] = *reinterpret_cast<const float4 *>(p.res + (i64)m * p.ldy + c);
+                        st.resv[r] = *reinterpret_cast<const f32x4 *>(p.res + (i64)m * p.ldy + c);
                     else if (p.table)
-                        st.resv[r] = *reinterpret_cast<const float4 *>(p.table + (i64)p0 * C2 + c);
+                        st.resv[r] = *reinterpret_cast<const f32x4 *>(p.table + (i64)p0 * C2 + c);
                 }
             }
         }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
 #pragma unroll
             for (int j = 0; j < NV4; ++j)
             {
-                float4 v = st.a4[s][j];
+                f32x4 v = st.a4[s][j];
                 if (PRO == PRO_AFFINE)
                 {
                     v.x = (v.x - aMean) * aScale, v.y = (v.y - aMean) * aScale;
@@ -233,12 +239,12 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                     v.w = dgelu((v.w - aMean) * aScale * gW4[j].w + gB4[j].w);
                 }
                 if (PRO != PRO_NONE && !((st.ok4 >> (s * NV4 + j)) & 1u))
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int fj = 0; fj < NF; ++fj)
-                        acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], c), f4get(v, c), acc[fj], 0, 0, 0);
+                        acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], c), v[c], acc[fj], 0, 0, 0);
             }
 #pragma unroll
             for (int c = 0; c < RPL; ++c)
@@ -316,8 +322,8 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                         const float4 bg = CST_LDS ? cst[0][fj + 1][h] : biasv[CST_LDS ? 0 : fj + 1];
                         float av[4] = {acc[fj][0] + ba.x, acc[fj][1] + ba.y, acc[fj][2] + ba.z, acc[fj][3] + ba.w};
                         float gv[4] = {acc[fj + 1][0] + bg.x, acc[fj + 1][1] + bg.y, acc[fj + 1][2] + bg.z, acc[fj + 1][3] + bg.w};
-                        const float4 r4 = st.resv[fj >> 1];
-                        const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                        const f32x4 r4 = st.resv[fj >> 1];
+                        const float rv[4] = {r4[0], r4[1], r4[2], r4[3]};
                         float ov[4];
                         if (EPI == EPI_GN_GLU_SCALE_RES)
                         {

@@ -42,7 +42,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float f4c(const f32x4 &v, int c) { return v[c]; }
+// `ok ? *ptr : zero` as written selects between a global pointer and a private temporary and loads
+// through a FLAT pointer (plus a scratch slot); select the address against the zero page instead
+__device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *zero)
+{
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? ptr : zero);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
@@ -142,7 +149,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
         bRow[i] = p.Wt + (i64)(bRowOk[i] ? n : 0) * p.Kp;
     }
 
-    float4 aReg[AR], bReg[BR], gW, gB;
+    // staging registers are NATIVE vectors: a float4 (struct) copied whole is lowered to a memcpy through a
+    // private-memory alloca that SROA does not split, i.e. the tile would travel global -> scratch -> LDS
+    f32x4 aReg[AR], bReg[BR], gW, gB;
     const int nk16 = p.Kp >> 4;
     const int nk = (nk16 + KS - 1) / KS;
 
@@ -191,14 +200,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            aReg[i] = *reinterpret_cast<const float4 *>(addrA[i]);
+            aReg[i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            bReg[i] = *reinterpret_cast<const float4 *>(addrB[i]);
+            bReg[i] = *reinterpret_cast<const f32x4 *>(addrB[i]);
         if (PRO == PRO_GN_GELU)
         {
-            gW = *reinterpret_cast<const float4 *>(addrG);
-            gB = *reinterpret_cast<const float4 *>(addrG + (p.proB - p.proW));
+            gW = *reinterpret_cast<const f32x4 *>(addrG);
+            gB = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
         }
         maskHeld = maskNext;
     };
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #pragma unroll
         for (int i = 0; i < AR; ++i)
         {
-            float4 v = aReg[i];
+            f32x4 v = aReg[i];
             if (PRO != PRO_NONE)
             {
                 const bool ok = (maskHeld >> i) & 1u;
@@ -228,16 +237,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                     v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW.w + gB.w);
                 }
                 if (!ok)
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            As[buf][slane][(srow + i * RP) ^ (slane * SWM)] = v;
+            *reinterpret_cast<f32x4 *>(&As[buf][slane][(srow + i * RP) ^ (slane * SWM)]) = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
         {
             const int rl = srow + i * RP;
             if (BN % RP == 0 || rl < BN)
-                Bs[buf][slane][rl ^ (slane * SWM)] = bReg[i];
+                *reinterpret_cast<f32x4 *>(&Bs[buf][slane][rl ^ (slane * SWM)]) = bReg[i];
         }
     };
 
@@ -279,13 +288,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #pragma unroll
         for (int ch = 0; ch < KS; ++ch)
         {
-            float4 a[WMF], b[WNF];
+            f32x4 a[WMF], b[WNF];
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
-                a[i] = As[cur][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)];
+                a[i] = *reinterpret_cast<const f32x4 *>(&As[cur][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                b[j] = Bs[cur][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)];
+                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
             // k sub-step outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
             // MFMA has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     {
         const int n = colBase + j * 16;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        biasv[j] = n < p.N ? *reinterpret_cast<const float4 *>(p.bias + n) : z;
+        biasv[j] = ld4z(p.bias + n, n < p.N, p.zero);
         scalev[j] = gnWv[j] = gnBv[j] = z;
         trR[j] = trC[j] = 0;
         if (EPI == EPI_TRCONV)
@@ -410,7 +419,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                 s += __shfl_xor(s, 32);
                 ss += __shfl_xor(ss, 32);
                 if (kq == 0)
-                    rsum[rl][wn] = make_float2(s, ss);
+                {
+                    rsum[rl][wn].x = s; // member-wise: a whole-struct store goes through a private-memory temporary
+                    rsum[rl][wn].y = ss;
+                }
             }
         }
         else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Effective shader clock per kernel class under the bench workload: GRBM_GUI_ACTIVE (cycles the GPU
+# was busy during the dispatch) / kernel duration (MI355X_MICROARCH.md §DVFS give-back). Own PMC pass.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+B=${1:-12}
+mkdir -p $R/gpurun_out/pmc
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d /tmp/pmcE -o e -- $CMD > /tmp/pmcE.log 2>&1
+f=$(find /tmp/pmcE -name "*.db" | head -1)
+tail -2 /tmp/pmcE.log
+python $R/tools/pmc_summary.py $f --class > $R/gpurun_out/pmc/pass_E_class.csv
+python - <<PY
+import csv
+rows = list(csv.DictReader(open("$R/gpurun_out/pmc/pass_E_class.csv")))
+print("class,calls,avg_us,effective_clock_GHz")
+for r in rows[:12]:
+    cyc = float(r.get("GRBM_GUI_ACTIVE", 0) or 0)
+    us = float(r["total_us"])
+    if us > 0 and cyc > 0:
+        print(f'{r["kernel"]},{r["calls"]},{r["avg_us"]},{cyc / us / 1e3:.3f}')
+PY
