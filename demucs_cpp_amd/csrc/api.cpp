@@ -97,7 +97,8 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
         return fail(DMX_ERR_ARG, "dmx_model_load: device %d out of range (have %d)", device, ndev);
     m->device = device;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float)));
+    // + 256 B: the igemm staging prefetches one K-tile beyond the last one (never used, must be readable)
+    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 256));
     HIPCHK(hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = m.release();
     return DMX_OK;

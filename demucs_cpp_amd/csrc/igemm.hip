@@ -51,7 +51,10 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI>
+// LIN: "linear layer" addressing - one contiguous run of K floats per row (S1 == 1, no padding, K a
+// multiple of the K-tile): the staging addresses of a row just advance by one K-tile per iteration, no
+// per-tile bounds checks, tap bookkeeping or pointer selects (transformer linears, 1x1 rewrites).
+template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 {
     constexpr int BM = WAVES_M * WMF * 16;
@@ -170,7 +173,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
         }
     const float *addrA[AR], *addrB[BR], *addrG = p.zero;
     unsigned maskNext = 0, maskHeld = 0;
+    i64 stepA[AR], stepB[BR]; // LIN: per-row advance (0 for rows that stay on the zero page)
+    bool linInit = false;
     auto compute_addrs = [&]() {
+        if (LIN)
+        {
+            if (!linInit)
+            {
+                linInit = true;
+                maskNext = 0;
+#pragma unroll
+                for (int i = 0; i < AR; ++i)
+                {
+                    addrA[i] = aRowOk[i] ? aRow[i] + slane * 4 : p.zero;
+                    stepA[i] = aRowOk[i] ? 16 * KS : 0;
+                    maskNext |= (aRowOk[i] ? 1u : 0u) << i;
+                }
+#pragma unroll
+                for (int i = 0; i < BR; ++i)
+                {
+                    addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
+                    stepB[i] = bRowOk[i] ? 16 * KS : 0;
+                }
+                if (PRO == PRO_GN_GELU)
+                    addrG = p.proW + slane * 4;
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                addrA[i] += stepA[i];
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                addrB[i] += stepB[i];
+            if (PRO == PRO_GN_GELU)
+                addrG += 16 * KS;
+            return;
+        }
         maskNext = 0;
         const bool kOk = kl < p.K;
         const int segOff = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
@@ -545,6 +583,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 }
 
 template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
+static bool is_linear(const GemmArgs &a)
+{
+    return PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2 && a.S1 == 1 && a.pad0 == 0 &&
+           a.seg0 == a.K && a.K == a.Kp && a.K % (16 * KS) == 0 && a.Np % 4 == 0 &&
+           (i64)(a.P0 - 1) * a.stride0 * a.Cin + a.seg0 <= (i64)a.L0 * a.Cin && a.P1 == a.L1 && a.stride1 == 1 && a.pad1 == 0;
+}
+
+template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
 static void launch_one(const GemmArgs &a0, hipStream_t s)
 {
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
@@ -555,7 +601,16 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
     a.xcdMap = xcdMap;
     const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
     static const int padLds = getenv("DMX_IGEMM_PADLDS") ? atoi(getenv("DMX_IGEMM_PADLDS")) : 0; // experiment: limit residency
-    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI>), dim3(blocks), dim3(256), padLds, s, a);
+    static const int linOn = getenv("DMX_IGEMM_LIN") ? atoi(getenv("DMX_IGEMM_LIN")) : 1;
+    if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2)
+    {
+        if (linOn && is_linear<WM_, WN_, MF, NF, KS, PRO, EPI>(a))
+        {
+            hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true>), dim3(blocks), dim3(256), padLds, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false>), dim3(blocks), dim3(256), padLds, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the
