@@ -30,12 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float a4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 template <int HS, int QF>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
 {
     constexpr int DQ = HS / 4;  // dim quads
     constexpr int DF = HS / 16; // dim fragments
     constexpr int KT = 64;      // keys per tile
-    constexpr int NL = (KT * DQ + 255) / 256; // float4 loads per thread per tile (K and V each)
+    constexpr int NL = (KT * DQ) / 256; // float4 loads per thread per tile (K and V each)
     constexpr int VLD = HS + 4;               // padded V row (floats)
     __shared__ float4 Ks[2][DQ][KT];
     __shared__ float Vs[2][KT][VLD];
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
     const float *V = p.v + (i64)b * p.vB + head * HS;
 
     // Q fragments: lane holds Q[q0 + 16 f + l15][16kk + 4h4 .. +3]
+    // pre-multiplied by scale * log2(e): the scores leave the MFMAs in the exp2 domain (softmax is
+    // invariant; for d_h = 64 the scale 1/8 is exact, so only the log2(e) factor adds one rounding)
+    const float qs = p.scale * 1.44269504088896340736f;
     float4 qf[QF][DF];
 #pragma unroll
     for (int f = 0; f < QF; ++f)
@@ -74,26 +77,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
         const int qr = q0 + 16 * f + l15;
 #pragma unroll
         for (int kk = 0; kk < DF; ++kk)
-            qf[f][kk] = qr < p.Tq ? *reinterpret_cast<const float4 *>(Q + (i64)qr * p.ldq + 16 * kk + 4 * h4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Q + (i64)min(qr, p.Tq - 1) * p.ldq + 16 * kk + 4 * h4);
+            qf[f][kk] = make_float4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs); // rows >= Tq: duplicates, never stored
+        }
     }
 
-    float4 kreg[NL], vreg[NL];
+    // staging: branch-free loads into native vectors; keys beyond Tk re-read the last valid row (their
+    // scores are masked to -inf in the last tile, so P = 0 meets finite V values)
+    static_assert((KT * DQ) % 256 == 0, "whole staging passes");
+    f32x4 kreg[NL], vreg[NL];
     auto load_tile = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < NL; ++i)
         {
             const int idx = tid + i * 256;
             const int key = idx / DQ, dq = idx - key * DQ;
-            const bool ok = idx < KT * DQ && t0 + key < p.Tk;
-            const i64 r = ok ? (i64)(t0 + key) : 0;
-            kreg[i] = *reinterpret_cast<const float4 *>(K + r * p.ldk + 4 * dq);
-            vreg[i] = *reinterpret_cast<const float4 *>(V + r * p.ldv + 4 * dq);
-            if (!ok)
-            {
-                kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const i64 r = min(t0 + key, p.Tk - 1);
+            kreg[i] = *reinterpret_cast<const f32x4 *>(K + r * p.ldk + 4 * dq);
+            vreg[i] = *reinterpret_cast<const f32x4 *>(V + r * p.ldv + 4 * dq);
         }
     };
     auto store_tile = [&](int buf) {
@@ -102,11 +104,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
         {
             const int idx = tid + i * 256;
             const int key = idx / DQ, dq = idx - key * DQ;
-            if (idx < KT * DQ)
-            {
-                Ks[buf][dq][key ^ (2 * (dq & 3))] = kreg[i];
-                *reinterpret_cast<float4 *>(&Vs[buf][key][4 * dq]) = vreg[i];
-            }
+            *reinterpret_cast<f32x4 *>(&Ks[buf][dq][key ^ (2 * (dq & 3))]) = kreg[i];
+            *reinterpret_cast<f32x4 *>(&Vs[buf][key][4 * dq]) = vreg[i];
         }
     };
 
@@ -123,15 +122,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
     }
 
     const int nt = (p.Tk + KT - 1) / KT;
+    const bool partial = (p.Tk % KT) != 0;
     load_tile(0);
     store_tile(0);
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < nt; ++t)
     {
-        const bool next = t + 1 < nt;
-        if (next)
-            load_tile((t + 1) * KT);
+        load_tile((t + 1) * KT); // beyond the end: clamped re-read, never stored
         // ---- S^T = K Q^T : 4 key fragments x QF query fragments; dim step outermost so that
         // consecutive MFMAs hit different accumulators
         f32x4 sT[QF][4];
@@ -159,29 +157,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
 #pragma unroll
         for (int f = 0; f < QF; ++f)
         {
-            float tmax = -INFINITY;
+            if (t == nt - 1 && partial) // uniform: only the last tile of a Tk that is not a multiple of 64
+            {
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                {
-                    const int key = t * KT + 16 * kf + 4 * h4 + r;
-                    float s = sT[f][kf][r] * p.scale;
-                    s = key < p.Tk ? s : -INFINITY;
-                    sT[f][kf][r] = s;
-                    tmax = fmaxf(tmax, s);
-                }
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KT + 16 * kf + 4 * h4 + r >= p.Tk)
+                            sT[f][kf][r] = -INFINITY;
+            }
+            float tmax = fmaxf(fmaxf(sT[f][0][0], sT[f][0][1]), fmaxf(sT[f][0][2], sT[f][0][3]));
+#pragma unroll
+            for (int kf = 1; kf < 4; ++kf)
+                tmax = fmaxf(tmax, fmaxf(fmaxf(sT[f][kf][0], sT[f][kf][1]), fmaxf(sT[f][kf][2], sT[f][kf][3])));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float mnew = fmaxf(mrun[f], tmax);
-            const float alpha = __expf(mrun[f] - mnew); // first tile: exp(-inf) = 0
+            const float alpha = exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
             float psum = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                 {
-                    const float pv = __expf(sT[f][kf][r] - mnew);
+                    const float pv = exp2f(sT[f][kf][r] - mnew);
                     sT[f][kf][r] = pv;
                     psum += pv;
                 }
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p)
                     for (int f = 0; f < QF; ++f)
                         o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
         }
-        if (next)
+        if (t + 1 < nt)
             store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;

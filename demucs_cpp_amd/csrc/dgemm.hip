@@ -22,7 +22,7 @@ namespace dmx
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float dgelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu(float v) { return dmx_gelu(v); }
 __device__ __forceinline__ float dsigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f)
 {

@@ -40,7 +40,7 @@ namespace dmx
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float v) { return dmx_gelu(v); }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float f4c(const f32x4 &v, int c) { return v[c]; }
 // `ok ? *ptr : zero` as written selects between a global pointer and a private temporary and loads

@@ -136,4 +136,33 @@ void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride,
 // interleaved <-> planar helpers
 void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream_t s);
 
+
+#ifdef __HIPCC__
+// erf for the exact GELU 0.5 v (1 + erf(v / sqrt 2)) (/root/reference/src/layers.hpp:51-63, conv.hpp:203-204).
+// Branch-free two-range minimax fit, max abs error 9.7e-8 (~1.6 ulp at 1) against scipy.special.erf over
+// [-6, 6] in fp32 arithmetic (fit + check: DESIGN.md section 2.2): |x| < 0.92: x * A(x^2);
+// else sign(x) * (1 - 2^B(min(|x|, 4))). 19 VALU instructions incl. one v_exp_f32; the ocml erff costs
+// ~45 on a wave whose lanes straddle its two ranges, and a 128x128 GELU epilogue evaluates 64 per lane.
+__device__ __forceinline__ float dmx_erff(float x)
+{
+    const float t = fminf(fabsf(x), 4.0f);
+    const float s = x * x;
+    float a = fmaf(-0.0005843715625815094f, s, 0.004958246368914843f);
+    a = fmaf(a, s, -0.026736384257674217f);
+    a = fmaf(a, s, 0.11280667781829834f);
+    a = fmaf(a, s, -0.3761231601238251f);
+    a = fmaf(a, s, 1.1283791065216064f);
+    a *= x;
+    float b = fmaf(0.0002812488819472492f, t, -0.004376694560050964f);
+    b = fmaf(b, t, 0.03201308846473694f);
+    b = fmaf(b, t, -0.149833083152771f);
+    b = fmaf(b, t, -0.9193801283836365f);
+    b = fmaf(b, t, -1.6268224716186523f);
+    b = fmaf(b, t, -0.0002986486360896379f);
+    const float r = copysignf(1.0f - __builtin_amdgcn_exp2f(b), x);
+    return t < 0.92f ? a : r;
+}
+__device__ __forceinline__ float dmx_gelu(float v) { return 0.5f * v * (1.0f + dmx_erff(v * 0.70710678118654752440f)); }
+#endif
+
 } // namespace dmx
