@@ -37,7 +37,7 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
 }
 __device__ __forceinline__ float f4get(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
-template <int NF, int S1, int SEG0, int PRO, int EPI>
+template <int NF, int S1, int SEG0, int PRO, int EPI, int PIPE>
 __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const FastDiv dP0, const FastDiv dP1)
 {
     constexpr int NV4 = SEG0 / 16;          // float4 steps per contiguous run
@@ -269,15 +269,8 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         float s = 0.f, ss = 0.f;
         if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY)
         {
-            float4 resv[NF];
-#pragma unroll
-            for (int fj = 0; fj < NF; ++fj)
-            {
-                const int n = fj * 16 + 4 * h;
-                resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (EPI == EPI_LINEAR && p.res && eOk && n < p.N)
-                    resv[fj] = *reinterpret_cast<const float4 *>(p.res + em * p.ldy + n);
-            }
+            // no residual operand here (launch_dgemm refuses shapes that carry one): a load issued in the
+            // epilogue would have to be waited for with vmcnt(0), i.e. behind the whole prefetched stage
 #pragma unroll
             for (int fj = 0; fj < NF; ++fj)
             {
@@ -290,7 +283,6 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                     {
                         if (p.act)
                             v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
-                        v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
                         *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
                     }
                     s += (v.x + v.y) + (v.z + v.w);
@@ -357,21 +349,12 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         else // EPI_TRCONV
         {
             i64 offs[NF];
-            float4 resv[NF];
 #pragma unroll
             for (int fj = 0; fj < NF; ++fj)
             {
                 const int n = fj * 16 + 4 * h;
                 const int jj = 4 * p0 + trR[fj] - 2;
                 offs[fj] = (eOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)b * p.yBS + ((i64)p1 * p.Lout + jj) * p.ldy + trC[fj] : -1;
-                resv[fj] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (p.res)
-            {
-#pragma unroll
-                for (int fj = 0; fj < NF; ++fj)
-                    if (offs[fj] >= 0)
-                        resv[fj] = *reinterpret_cast<const float4 *>(p.res + offs[fj]);
             }
 #pragma unroll
             for (int fj = 0; fj < NF; ++fj)
@@ -381,19 +364,45 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                     float4 v = make_float4(acc[fj][0] + bi.x, acc[fj][1] + bi.y, acc[fj][2] + bi.z, acc[fj][3] + bi.w);
                     if (p.act)
                         v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
-                    v.x += resv[fj].x, v.y += resv[fj].y, v.z += resv[fj].z, v.w += resv[fj].w;
                     *reinterpret_cast<float4 *>(p.Y + offs[fj]) = v;
                 }
         }
     };
 
-    Stage cur, nxt;
-    fetch(gwave, cur);
-    for (int frag = gwave; frag < nfrag; frag += nwaves)
+    // Fragment pipeline. PIPE 0: one hand-over `cur = nxt` (the register allocator coalesces both stages
+    // and sinks the prefetch behind the last MFMA that reads it: smallest footprint, most waves per SIMD);
+    // PIPE 1: two explicit stages, loop unrolled by two, scheduler free; PIPE 2: same with the prefetch
+    // pinned ahead of the other stage's MFMAs. Chosen per kernel shape from measurements (launch table).
+    if constexpr (PIPE == 0)
     {
-        fetch(frag + nwaves, nxt); // beyond the end: every load goes to the zero page
-        compute(cur);
-        cur = nxt;
+        Stage cur, nxt;
+        fetch(gwave, cur);
+        for (int frag = gwave; frag < nfrag; frag += nwaves)
+        {
+            fetch(frag + nwaves, nxt); // beyond the end: every load goes to the zero page
+            compute(cur);
+            cur = nxt;
+        }
+    }
+    else
+    {
+        Stage sa, sb;
+        fetch(gwave, sa);
+        for (int frag = gwave; frag < nfrag; frag += 2 * nwaves)
+        {
+            fetch(frag + nwaves, sb); // beyond the end: every load goes to the zero page, nothing is stored
+            if (PIPE == 2)
+                __builtin_amdgcn_sched_barrier(0);
+            compute(sa);
+            if (PIPE == 2)
+                __builtin_amdgcn_sched_barrier(0);
+            fetch(frag + 2 * nwaves, sa);
+            if (PIPE == 2)
+                __builtin_amdgcn_sched_barrier(0);
+            compute(sb);
+            if (PIPE == 2)
+                __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -418,14 +427,18 @@ static FastDiv make_fastdiv(unsigned d)
     return f;
 }
 
-template <int NF, int S1, int SEG0, int PRO, int EPI>
+#ifndef DMX_DG_PIPE
+#define DMX_DG_PIPE -1 // -1: per-shape choice of the launch table; 0/1/2 force one pipeline (experiments)
+#endif
+template <int NF, int S1, int SEG0, int PRO, int EPI, int PIPE_>
 static void launch_d(const GemmArgs &a, hipStream_t s)
 {
     const int nfrag = (int)((a.M + 15) >> 4);
     int blocks = (nfrag + 3) / 4;
     if (blocks > 256 * 8)
         blocks = 256 * 8; // persistent: 8 workgroups per CU at most, waves stride over fragments
-    hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI>), dim3(blocks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
+    constexpr int PIPE = DMX_DG_PIPE >= 0 ? DMX_DG_PIPE : PIPE_;
+    hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI, PIPE>), dim3(blocks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
                        make_fastdiv((unsigned)a.P1));
 }
 
@@ -436,31 +449,33 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
     const int NF = (a.N + 15) / 16;
     if (a.M >= (1ll << 31) - 16 || (i64)a.L0 * a.Cin >= (1ll << 31))
         return -1;
-#define DMX_D(NF_, S1_, SEG_, PRO_, EPI_)                                     \
+    if ((a.epi == EPI_LINEAR || a.epi == EPI_TRCONV) && a.res)
+        return -1; // residual adds of these epilogues stay with the LDS-tiled kernel
+#define DMX_D(NF_, S1_, SEG_, PRO_, EPI_, PIPE_)                              \
     case (NF_ * 1000000 + S1_ * 100000 + SEG_ * 100 + PRO_ * 10 + EPI_):      \
         if (!dry)                                                             \
-            launch_d<NF_, S1_, SEG_, PRO_, EPI_>(a, s);                       \
+            launch_d<NF_, S1_, SEG_, PRO_, EPI_, PIPE_>(a, s);                \
         return 0;
     switch (NF * 1000000 + a.S1 * 100000 + a.seg0 * 100 + a.pro * 10 + a.epi)
     {
         // DConv k1: Conv1d(C -> C/8, k3): C = 48, 96
-        DMX_D(1, 3, 48, PRO_NONE, EPI_LINEAR)
-        DMX_D(1, 3, 96, PRO_NONE, EPI_LINEAR)
+        DMX_D(1, 3, 48, PRO_NONE, EPI_LINEAR, 0)
+        DMX_D(1, 3, 96, PRO_NONE, EPI_LINEAR, 1)
         // DConv k2 / k3: hidden 8 (C=48) / 12 (C=96) -> 2C, statistics / final
-        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_STATS_ONLY)
-        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_STATS_ONLY)
-        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_STATS_ONLY, 2)
+        DMX_D(6, 1, 8, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0)
+        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_STATS_ONLY, 0)
+        DMX_D(12, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1)
         // first encoder convs (z-norm prologue) k8 s4: Cin = 4 (freq), 2 (time)
-        DMX_D(3, 1, 32, PRO_AFFINE, EPI_LINEAR)
-        DMX_D(3, 1, 16, PRO_AFFINE, EPI_LINEAR)
+        DMX_D(3, 1, 32, PRO_AFFINE, EPI_LINEAR, 0)
+        DMX_D(3, 1, 16, PRO_AFFINE, EPI_LINEAR, 0)
         // level-0 rewrites 48 -> 96 + GLU
-        DMX_D(6, 1, 48, PRO_NONE, EPI_GLU)
+        DMX_D(6, 1, 48, PRO_NONE, EPI_GLU, 0)
         // last transposed convs 48 -> 4*Cout: Cout = 16 / 8 (4 sources), 24 / 12 (6 sources)
-        DMX_D(4, 1, 96, PRO_NONE, EPI_TRCONV)
-        DMX_D(2, 1, 96, PRO_NONE, EPI_TRCONV)
-        DMX_D(6, 1, 96, PRO_NONE, EPI_TRCONV)
-        DMX_D(3, 1, 96, PRO_NONE, EPI_TRCONV)
+        DMX_D(4, 1, 96, PRO_NONE, EPI_TRCONV, 0)
+        DMX_D(2, 1, 96, PRO_NONE, EPI_TRCONV, 0)
+        DMX_D(6, 1, 96, PRO_NONE, EPI_TRCONV, 0)
+        DMX_D(3, 1, 96, PRO_NONE, EPI_TRCONV, 0)
     default:
         return -1;
     }

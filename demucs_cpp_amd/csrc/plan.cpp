@@ -127,8 +127,10 @@ struct Builder
         g.xBatchStride = (i64)g.L1 * g.L0 * g.Cin;
         g.cfg = choose_cfg((i64)g.P1 * g.P0, g.N, paired);
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
-        if (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
-            (g.epi == EPI_STATS_ONLY && direct_available(g.N, g.S1, g.seg0, g.pro, EPI_GN_GLU_SCALE_RES)))
+        // (the direct kernels carry no residual operand for the LINEAR / TRCONV epilogues)
+        const bool resOk = !((g.epi == EPI_LINEAR || g.epi == EPI_TRCONV) && g.res >= 0);
+        if (resOk && (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
+                      (g.epi == EPI_STATS_ONLY && direct_available(g.N, g.S1, g.seg0, g.pro, EPI_GN_GLU_SCALE_RES))))
             g.cfg = kDirectCfg;
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
     }
