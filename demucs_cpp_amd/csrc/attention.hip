@@ -245,8 +245,12 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
     a.xcdMap = xcdMap;
     // 32 queries per wave (128 per workgroup) when that still leaves >= 2 rounds of workgroups per CU;
     // the key-tile order, hence every rounding, is the same for both shapes
-    const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B;
-    const bool big = wg128 >= 1024;
+    // (rounds of the 512 resident workgroups) x (relative duration of one workgroup): the 64-query
+    // shape does ~0.6x the work of the 128-query one per workgroup (K/V LDS reads amortised over half the
+    // queries); e.g. Tq = 1344 at batch 12 is 1056 big workgroups = 2.06 rounds -> 3, or 2016 small = 3.94 -> 4 x 0.6
+    const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B, wg64 = (long)((a.Tq + 63) / 64) * a.H * a.B;
+    const double costBig = (double)((wg128 + 511) / 512), costSmall = 0.6 * (double)((wg64 + 511) / 512);
+    const bool big = costBig <= costSmall;
     if (a.hs != 64 && a.hs != 48)
         abort();
     a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);
