@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: TEST MODE ONLY - several ranks share GPU 0 and the gather goes through host memory, to "
+                         "exercise the N > 1 control flow (double buffering, flush, overlap-add of all ranks' segments) on a "
+                         "1-GPU box; the numbers it prints are not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -87,13 +91,19 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    test_mode = args.backend == "gloo"
+    if test_mode:
+        local_rank = 0  # every rank on GPU 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if test_mode:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     B = args.batch
     S = 4
@@ -136,6 +146,21 @@ def main():
     state = {"pending": None}
     torch.cuda.synchronize()
 
+    class HostGather:
+        """test mode: gloo gather through host memory with the interface of an async Work"""
+
+        def __init__(self, src, dst_views):
+            stream.synchronize()
+            h = src.cpu()
+            lst = [torch.empty_like(h) for _ in range(world)] if rank == 0 else None
+            dist.gather(h, lst, dst=0)
+            if rank == 0:
+                for v, t in zip(dst_views, lst):
+                    v.copy_(t)
+
+        def wait(self):
+            pass
+
     def finish(slot):
         """root: triangle-weighted overlap-add of the step held in `slot` (after its gather landed)"""
         if world > 1:
@@ -147,7 +172,9 @@ def main():
         if world > 1 and works[slot] is not None:
             works[slot].wait()  # the gather that last read outs[slot] (step i-2) is complete before it is overwritten
         ctx.segment_device(mix.data_ptr(), outs[slot].data_ptr(), B)
-        if world > 1:
+        if world > 1 and test_mode:
+            works[slot] = HostGather(outs[slot], gathered[slot] if rank == 0 else None)
+        elif world > 1:
             works[slot] = dist.gather(outs[slot], gathered[slot] if rank == 0 else None, dst=0, async_op=True)
         if rank == 0:
             if state["pending"] is not None:
@@ -164,6 +191,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    check = None
+    if test_mode and rank == 0:
+        check = {"track": None}
+
     for i in range(args.warmup):
         step(i)
     flush()
@@ -179,6 +210,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = outs[(args.steps - 1) & 1] if args.steps > 0 else outs[0]
+    if test_mode and world > 1:
+        # every rank computed the same segments here?  No: ranks use different seeds; the root checks that the
+        # track it overlap-added from the gathered slabs equals the overlap-add of the slabs recomputed locally
+        torch.cuda.synchronize()
+        slot = (args.steps - 1) & 1
+        if rank == 0:
+            ref = torch.zeros_like(track_out)
+            parts = []
+            for r in range(world):
+                g = torch.Generator(device="cpu").manual_seed(1000 + r)
+                mr = (0.1 * torch.randn((B, SEG, 2), generator=g)).cuda()
+                o = torch.zeros((B, S, 2, SEG), device="cuda")
+                ctx.segment_device(mr.data_ptr(), o.data_ptr(), B)
+                parts.append(o)
+            allref = torch.cat(parts, dim=0)
+            ctx.track_overlap_add_device(allref.data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), ref.data_ptr())
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref, track_out)) and bool(torch.equal(allref, allseg[slot]))
+            print(f"[test mode] world={world}: gathered slabs and overlap-added track bit-identical to a local recomputation: {same}", flush=True)
+            if not same:
+                raise SystemExit(3)
 
     finite = bool(torch.isfinite(out).all().item())
 
