@@ -103,3 +103,7 @@ def test_product_does_not_reference_the_oracle():
                 if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "oracle_lib" not in txt and "liboracle" not in txt and "cpu_interp" not in txt.replace("tests/cpu_interp.cpp", ""), os.path.join(dp, f)
+                    # no include / import / dlopen of anything that lives under oracle/ (comments may cite it)
+                    import re
+                    for ln in txt.splitlines():
+                        assert not re.search(r"(#\s*include|\bimport\b|\bfrom\b|dlopen|CDLL)[^\n]*(oracle|threaded_split)", ln), (os.path.join(dp, f), ln)
