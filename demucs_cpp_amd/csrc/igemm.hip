@@ -54,9 +54,14 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
 // LIN: "linear layer" addressing - one contiguous run of K floats per row (S1 == 1, no padding, K a
 // multiple of the K-tile): the staging addresses of a row just advance by one K-tile per iteration, no
 // per-tile bounds checks, tap bookkeeping or pointer selects (transformer linears, 1x1 rewrites).
-template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
+// IL: interleaved main loop (KS == 2). Instead of three phases per K-tile [issue loads | MFMA block |
+// ds_write + addresses], the ds_writes of tile t+1 and the global loads of tile t+2 are issued in eight
+// small pieces BETWEEN the eight 16-MFMA groups of tile t (pinned with sched_barrier), so a wave's
+// instruction stream is a uniform MFMA-dominated mix with no long matrix-idle stretch.
+template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN, bool IL>
+__global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmArgs p)
 {
+    static_assert(!IL || KS == 2, "interleaved loop is written for 2 k-chunks per tile");
     constexpr int BM = WAVES_M * WMF * 16;
     constexpr int BN = WAVES_N * WNF * 16;
     constexpr int LPR = 4 * KS;              // lanes per staged row: one float4 each = the row's 16*KS floats (full 128-B lines at KS=2)
@@ -175,12 +180,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     unsigned maskNext = 0, maskHeld = 0;
     i64 stepA[AR], stepB[BR]; // LIN: per-row advance (0 for rows that stay on the zero page)
     bool linInit = false;
-    auto compute_addrs = [&]() {
+    // addresses of the next tile to fetch, in two halves (the interleaved loop slots them between MFMA groups):
+    // addrs_A = validity + A row addresses, addrs_B = B row addresses + advance of the K walk
+    int segOffCur = 0;
+    bool kpOkCur = true;
+    auto addrs_A = [&]() {
         if (LIN)
         {
             if (!linInit)
             {
-                linInit = true;
                 maskNext = 0;
 #pragma unroll
                 for (int i = 0; i < AR; ++i)
@@ -189,12 +197,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
                     stepA[i] = aRowOk[i] ? 16 * KS : 0;
                     maskNext |= (aRowOk[i] ? 1u : 0u) << i;
                 }
-#pragma unroll
-                for (int i = 0; i < BR; ++i)
-                {
-                    addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
-                    stepB[i] = bRowOk[i] ? 16 * KS : 0;
-                }
                 if (PRO == PRO_GN_GELU)
                     addrG = p.proW + slane * 4;
                 return;
@@ -202,31 +204,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 addrA[i] += stepA[i];
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-                addrB[i] += stepB[i];
             if (PRO == PRO_GN_GELU)
                 addrG += 16 * KS;
             return;
         }
         maskNext = 0;
         const bool kOk = kl < p.K;
-        const int segOff = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
+        kpOkCur = kl < p.Kp;
+        segOffCur = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
 #pragma unroll
         for (int i = 0; i < AR; ++i)
         {
             const int in1 = aIn1[i] + s1 * p.dil1;
             const int e = aE0[i] + offb;
             const bool ok = kOk && aRowOk[i] && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLenI;
-            addrA[i] = ok ? aRow[i] + segOff : p.zero;
+            addrA[i] = ok ? aRow[i] + segOffCur : p.zero;
             maskNext |= (ok ? 1u : 0u) << i;
         }
-        const bool kpOk = kl < p.Kp;
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            addrB[i] = (kpOk && bRowOk[i]) ? bRow[i] + kl : p.zero;
         if (PRO == PRO_GN_GELU)
             addrG = p.proW + (kOk ? kl : 0);
+    };
+    auto addrs_B = [&]() {
+        if (LIN)
+        {
+            if (!linInit)
+            {
+                linInit = true;
+#pragma unroll
+                for (int i = 0; i < BR; ++i)
+                {
+                    addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
+                    stepB[i] = bRowOk[i] ? 16 * KS : 0;
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                addrB[i] += stepB[i];
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            addrB[i] = (kpOkCur && bRowOk[i]) ? bRow[i] + kl : p.zero;
         kl += 16 * KS;
         offb += 16 * KS;
         if (p.S1 > 1 && offb >= p.seg0)
@@ -234,6 +253,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
             offb -= p.seg0;
             ++s1;
         }
+    };
+    auto compute_addrs = [&]() {
+        addrs_A();
+        addrs_B();
     };
     auto issue_loads = [&]() {
 #pragma unroll
@@ -288,6 +311,74 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
         }
     };
 
+    // piece-wise staging for the interleaved loop: piece 0/1 = first / second half of the A rows,
+    // piece 2/3 = first / second half of the B rows
+    constexpr int AH = (AR + 1) / 2, BH = (BR + 1) / 2;
+    auto load_piece = [&](int piece) {
+        if (piece < 2)
+        {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                if ((i < AH) == (piece == 0))
+                    aReg[i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
+            if (PRO == PRO_GN_GELU && piece == 0)
+            {
+                gW = *reinterpret_cast<const f32x4 *>(addrG);
+                gB = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                if ((i < BH) == (piece == 2))
+                    bReg[i] = *reinterpret_cast<const f32x4 *>(addrB[i]);
+        }
+    };
+    auto store_piece = [&](int buf, int piece) {
+        if (piece < 2)
+        {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                if ((i < AH) == (piece == 0))
+                {
+                    f32x4 v = aReg[i];
+                    if (PRO != PRO_NONE)
+                    {
+                        const bool ok = (maskHeld >> i) & 1u;
+                        if (PRO == PRO_AFFINE)
+                        {
+                            v.x = (v.x - aMean[i]) * aScale[i];
+                            v.y = (v.y - aMean[i]) * aScale[i];
+                            v.z = (v.z - aMean[i]) * aScale[i];
+                            v.w = (v.w - aMean[i]) * aScale[i];
+                        }
+                        if (PRO == PRO_GN_GELU)
+                        {
+                            v.x = gelu_f((v.x - aMean[i]) * aScale[i] * gW.x + gB.x);
+                            v.y = gelu_f((v.y - aMean[i]) * aScale[i] * gW.y + gB.y);
+                            v.z = gelu_f((v.z - aMean[i]) * aScale[i] * gW.z + gB.z);
+                            v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW.w + gB.w);
+                        }
+                        if (!ok)
+                            v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    *reinterpret_cast<f32x4 *>(&As[buf][slane][(srow + i * RP) ^ (slane * SWM)]) = v;
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                if ((i < BH) == (piece == 2))
+                {
+                    const int rl = srow + i * RP;
+                    if (BN % RP == 0 || rl < BN)
+                        *reinterpret_cast<f32x4 *>(&Bs[buf][slane][rl ^ (slane * SWM)]) = bReg[i];
+                }
+        }
+    };
+
     f32x4 acc[WMF][WNF];
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
@@ -299,6 +390,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
     issue_loads();
     compute_addrs();
     store_tiles(0);
+    if (IL)
+    {
+        issue_loads(); // tile 1 stays in registers across the first iteration
+        compute_addrs();
+    }
     __syncthreads();
     int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -316,6 +412,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs p)
 #else
 #define DMX_TSTAMP(i)
 #endif
+    if constexpr (IL)
+    {
+        auto read_frags = [&](int buf, int ch, f32x4 *a, f32x4 *b) {
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+                a[i] = *reinterpret_cast<const f32x4 *>(&As[buf][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+        };
+        auto mfma16 = [&](const f32x4 *a, const f32x4 *b, int c) {
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < WNF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(b[j], c), f4c(a[i], c), acc[i][j], 0, 0, 0);
+        };
+        // ONE barrier per K-tile, in the MIDDLE of the iteration: the ds_writes of tile kt+1 all sit in the
+        // first half, every read of tile kt's LDS image too (its k-chunk 0 fragments were fetched at the end
+        // of the previous iteration, k-chunk 1 at group 1), so after the barrier tile kt+1 is complete and
+        // tile kt's buffer is free. The second half can therefore already fetch the first fragments of tile
+        // kt+1: no ds_read latency is exposed behind the barrier, and a wave waiting at the barrier sits
+        // between two MFMA groups while the co-resident workgroup keeps the matrix pipe busy.
+        f32x4 a0[WMF], b0[WNF], a1[WMF], b1[WNF];
+        read_frags(cur, 0, a0, b0);
+        for (int kt = 0; kt < nk; ++kt)
+        {
+            // k-chunk 0 of tile kt  |  ds_write of tile kt+1 (loaded one iteration ago) in four pieces
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                mfma16(a0, b0, c);
+                store_piece(cur ^ 1, c);
+                if (c == 1)
+                    read_frags(cur, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            // k-chunk 1  |  global loads of tile kt+2 into the registers just written out, the addresses
+            // of tile kt+3, the first fragments of tile kt+1
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                mfma16(a1, b1, c);
+                load_piece(c);
+                if (c == 1)
+                    maskHeld = maskNext; // validity of tile kt+2 (all A pieces issued)
+                if (c == 2)
+                {
+                    addrs_A();
+                    read_frags(cur ^ 1, 0, a0, b0);
+                }
+                if (c == 3)
+                    addrs_B();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur ^= 1;
+        }
+    }
+    else
     for (int kt = 0; kt < nk; ++kt)
     {
         issue_loads(); // tile kt+1 (zero page beyond the end: no branch)
@@ -602,15 +758,23 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
     const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
     static const int padLds = getenv("DMX_IGEMM_PADLDS") ? atoi(getenv("DMX_IGEMM_PADLDS")) : 0; // experiment: limit residency
     static const int linOn = getenv("DMX_IGEMM_LIN") ? atoi(getenv("DMX_IGEMM_LIN")) : 1;
+    static const int ilOn = getenv("DMX_IGEMM_IL") ? atoi(getenv("DMX_IGEMM_IL")) : 1;
+    constexpr bool CAN_IL = KS == 2;
     if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2)
     {
         if (linOn && is_linear<WM_, WN_, MF, NF, KS, PRO, EPI>(a))
         {
-            hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true>), dim3(blocks), dim3(256), padLds, s, a);
+            if (CAN_IL && ilOn)
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(256), padLds, s, a);
+            else
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, false>), dim3(blocks), dim3(256), padLds, s, a);
             return;
         }
     }
-    hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false>), dim3(blocks), dim3(256), padLds, s, a);
+    if (CAN_IL && ilOn)
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, CAN_IL>), dim3(blocks), dim3(256), padLds, s, a);
+    else
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, false>), dim3(blocks), dim3(256), padLds, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the
