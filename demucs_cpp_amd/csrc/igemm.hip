@@ -183,7 +183,30 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     // addresses of the next tile to fetch, in two halves (the interleaved loop slots them between MFMA groups):
     // addrs_A = validity + A row addresses, addrs_B = B row addresses + advance of the K walk
     int segOffCur = 0;
-    bool kpOkCur = true;
+    bool kpOkCur = true, kOkCur = true;
+    // general addressing of the A rows; half = 0 / 1: first / second half of the rows (the tile-wide
+    // quantities are set up with the first half), 2: all rows
+    auto addrs_A_general = [&](int half) {
+        if (half != 1)
+        {
+            maskNext = 0;
+            kOkCur = kl < p.K;
+            kpOkCur = kl < p.Kp;
+            segOffCur = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
+            if (PRO == PRO_GN_GELU)
+                addrG = p.proW + (kOkCur ? kl : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            if (half == 2 || (i < (AR + 1) / 2) == (half == 0))
+            {
+                const int in1 = aIn1[i] + s1 * p.dil1;
+                const int e = aE0[i] + offb;
+                const bool ok = kOkCur && aRowOk[i] && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLenI;
+                addrA[i] = ok ? aRow[i] + segOffCur : p.zero;
+                maskNext |= (ok ? 1u : 0u) << i;
+            }
+    };
     auto addrs_A = [&]() {
         if (LIN)
         {
@@ -208,21 +231,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
                 addrG += 16 * KS;
             return;
         }
-        maskNext = 0;
-        const bool kOk = kl < p.K;
-        kpOkCur = kl < p.Kp;
-        segOffCur = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-        {
-            const int in1 = aIn1[i] + s1 * p.dil1;
-            const int e = aE0[i] + offb;
-            const bool ok = kOk && aRowOk[i] && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLenI;
-            addrA[i] = ok ? aRow[i] + segOffCur : p.zero;
-            maskNext |= (ok ? 1u : 0u) << i;
-        }
-        if (PRO == PRO_GN_GELU)
-            addrG = p.proW + (kOk ? kl : 0);
+        addrs_A_general(2);
     };
     auto addrs_B = [&]() {
         if (LIN)
@@ -257,6 +266,21 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     auto compute_addrs = [&]() {
         addrs_A();
         addrs_B();
+    };
+    // the same work in pieces for the interleaved loop (piece c goes behind MFMA group c of k-chunk 0)
+    auto addr_piece = [&](int c) {
+        if (LIN)
+        {
+            if (c == 0)
+                addrs_A();
+            if (c == 2)
+                addrs_B();
+            return;
+        }
+        if (c < 2)
+            addrs_A_general(c);
+        if (c == 2)
+            addrs_B();
     };
     auto issue_loads = [&]() {
 #pragma unroll
@@ -391,10 +415,8 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     compute_addrs();
     store_tiles(0);
     if (IL)
-    {
-        issue_loads(); // tile 1 stays in registers across the first iteration
-        compute_addrs();
-    }
+        issue_loads(); // tile 1 stays in registers across the first iteration; the loop computes the
+                       // addresses of tile kt+2 in its first half and issues its loads in the second
     __syncthreads();
     int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -439,33 +461,30 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
         read_frags(cur, 0, a0, b0);
         for (int kt = 0; kt < nk; ++kt)
         {
-            // k-chunk 0 of tile kt  |  ds_write of tile kt+1 (loaded one iteration ago) in four pieces
+            // k-chunk 0 of tile kt  |  ds_write of tile kt+1 (loaded one iteration ago) and the addresses of
+            // tile kt+2, each in four pieces
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a0, b0, c);
                 store_piece(cur ^ 1, c);
+                addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
                 if (c == 1)
                     read_frags(cur, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
+                if (c == 3)
+                    maskHeld = maskNext; // tile kt+1 is written out: from here on the validity of tile kt+2
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            // k-chunk 1  |  global loads of tile kt+2 into the registers just written out, the addresses
-            // of tile kt+3, the first fragments of tile kt+1
+            // k-chunk 1  |  global loads of tile kt+2 into the registers just written out, the first
+            // fragments of tile kt+1
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a1, b1, c);
                 load_piece(c);
-                if (c == 1)
-                    maskHeld = maskNext; // validity of tile kt+2 (all A pieces issued)
                 if (c == 2)
-                {
-                    addrs_A();
                     read_frags(cur ^ 1, 0, a0, b0);
-                }
-                if (c == 3)
-                    addrs_B();
                 __builtin_amdgcn_sched_barrier(0);
             }
             cur ^= 1;
