@@ -31,6 +31,9 @@
 #define DMX_PIN_LOADS 0
 #endif
 
+#ifndef DMX_SMALL_KS
+#define DMX_SMALL_KS 2
+#endif
 #ifndef DMX_CFG2_KS
 #define DMX_CFG2_KS 2
 #endif
@@ -828,15 +831,15 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 3: 128x48
-        DMX_CASE(3, 4, 1, 2, 3, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(3, 4, 1, 2, 3, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(3, 4, 1, 2, 3, 1, PRO_AFFINE, EPI_LINEAR)
+        DMX_CASE(3, 4, 1, 2, 3, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(3, 4, 1, 2, 3, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(3, 4, 1, 2, 3, DMX_SMALL_KS, PRO_AFFINE, EPI_LINEAR)
         // cfg 4: 256x16, cfg 5: 128x32, cfg 6: 128x64
-        DMX_CASE(4, 4, 1, 4, 1, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(5, 4, 1, 2, 2, 1, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(5, 4, 1, 2, 2, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(6, 4, 1, 2, 4, 1, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(6, 4, 1, 2, 4, 1, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(4, 4, 1, 4, 1, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
     default:
         return -1;
     }
