@@ -27,10 +27,6 @@
 #include "kernels.h"
 #include <cstdlib>
 
-#ifndef DMX_PIN_LOADS
-#define DMX_PIN_LOADS 0
-#endif
-
 #ifndef DMX_SMALL_KS
 #define DMX_SMALL_KS 2
 #endif
@@ -497,9 +493,6 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     for (int kt = 0; kt < nk; ++kt)
     {
         issue_loads(); // tile kt+1 (zero page beyond the end: no branch)
-#if DMX_PIN_LOADS
-        __builtin_amdgcn_sched_barrier(0); // keep the loads AHEAD of the MFMA block (latency hiding)
-#endif
         DMX_TSTAMP(0);
 #pragma unroll
         for (int ch = 0; ch < KS; ++ch)
@@ -521,9 +514,6 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
                     for (int j = 0; j < WNF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(b[j], c), f4c(a[i], c), acc[i][j], 0, 0, 0); // operands swapped: C^T
         }
-#if DMX_PIN_LOADS
-        __builtin_amdgcn_sched_barrier(0); // ... and their first use BEHIND it
-#endif
         DMX_TSTAMP(1);
         store_tiles(cur ^ 1);
         DMX_TSTAMP(2);
@@ -778,7 +768,6 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
     a.tilesN = (unsigned)((a.N + BN - 1) / BN);
     a.xcdMap = xcdMap;
     const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
-    static const int padLds = getenv("DMX_IGEMM_PADLDS") ? atoi(getenv("DMX_IGEMM_PADLDS")) : 0; // experiment: limit residency
     static const int linOn = getenv("DMX_IGEMM_LIN") ? atoi(getenv("DMX_IGEMM_LIN")) : 1;
     static const int ilOn = getenv("DMX_IGEMM_IL") ? atoi(getenv("DMX_IGEMM_IL")) : 1;
     constexpr bool CAN_IL = KS == 2;
@@ -787,16 +776,16 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
         if (linOn && is_linear<WM_, WN_, MF, NF, KS, PRO, EPI>(a))
         {
             if (CAN_IL && ilOn)
-                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(256), padLds, s, a);
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(256), 0, s, a);
             else
-                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, false>), dim3(blocks), dim3(256), padLds, s, a);
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, false>), dim3(blocks), dim3(256), 0, s, a);
             return;
         }
     }
     if (CAN_IL && ilOn)
-        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, CAN_IL>), dim3(blocks), dim3(256), padLds, s, a);
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, CAN_IL>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, false>), dim3(blocks), dim3(256), padLds, s, a);
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Quick GPU iteration: parity tests + bench at batch 4 (+ per-op profile dump)
+# Quick GPU iteration: parity tests + bench + per-op profile dump at batch $PB (gpurun_out/profile_ops.tsv)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_gpu.log
 ( timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -3 ) > gpurun_out/bench.log
-for KS1 in 0; do export DMX_IGEMM_KS1=$KS1; echo "== DMX_IGEMM_KS1=$KS1"
+for once in 0; do
 ( timeout 600 python - <<'PY' 2>&1 | tail -60
 import sys, os
 sys.path.insert(0, os.getcwd())
@@ -13,7 +13,7 @@ from demucs_cpp_amd.weights import write_synthetic_model
 write_synthetic_model('/tmp/pm4.bin', 4, 0)
 m = dmx.Model('/tmp/pm4.bin'); ctx = dmx.Context(m, 0, int(os.environ.get("PB","4")))
 prof = ctx.profile(int(os.environ.get("PB","4")), 3)
-with open('gpurun_out/profile_ops_b4_ks1_%s.tsv' % os.environ.get('DMX_IGEMM_KS1','0'), 'w') as f:
+with open('gpurun_out/profile_ops.tsv', 'w') as f:
     for r in prof: f.write('\t'.join(str(x) for x in r) + '\n')
 agg = {}
 for nm, k, ms, fl, by in prof:
