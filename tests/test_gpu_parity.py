@@ -329,3 +329,24 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     import json
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["outputs_finite"] and d["scaling"] == "weak"
+
+
+def test_stream_schedule_does_not_change_a_bit(dmx, tmp_models, monkeypatch):
+    """One stream, two streams with the derived joins, and the automatic choice produce identical bits
+    (no atomics anywhere; reductions have a fixed order)."""
+    seg, B = 12000, 2
+    rng = np.random.default_rng(31)
+    mixes = (0.1 * rng.standard_normal((B, 2, seg))).astype(np.float32)
+    m = dmx.Model(tmp_models[4])
+    outs = []
+    for mode in ("1", "2", None):
+        if mode is None:
+            monkeypatch.delenv("DMX_STREAMS", raising=False)
+        else:
+            monkeypatch.setenv("DMX_STREAMS", mode)
+        ctx = dmx.Context(m, seg, B)
+        outs.append(np.stack([ctx.segment(mixes[b]) for b in range(B)]))
+        ctx.close()
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    m.close()
