@@ -173,14 +173,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float mnew = fmaxf(mrun[f], tmax);
-            const float alpha = exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
+            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
             float psum = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                 {
-                    const float pv = exp2f(sT[f][kf][r] - mnew);
+                    const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: arguments <= 0, underflow to 0 is the right answer
                     sT[f][kf][r] = pv;
                     psum += pv;
                 }
