@@ -14,12 +14,14 @@
 // every 16-lane ds_read_b128 group hits 16 distinct 16-byte slots and every 8-lane
 // ds_write_b128 group (2 rows x 4 k-quads) 8 distinct ones (conflict free both ways).
 //
-// Tile = (WAVES_M*WMF*16) x (WAVES_N*WNF*16) x (16*KS), 256 threads. The staging loads
-// of tile t+1 are issued branch-free (clamped addresses, validity kept as a bit mask)
-// BEFORE the MFMA block of tile t and only touched (prologue transform, zero fill,
-// ds_write) AFTER it, so global-load latency hides behind the matrix pipe; LDS is double
-// buffered, one barrier per K-tile. Prologue and epilogue kinds are template parameters
-// (one small specialised kernel per (tile, prologue, epilogue) used by the plan).
+// Tile = (WAVES_M*WMF*16) x (WAVES_N*WNF*16) x (16*KS), 256 threads, LDS double buffered, staging loads
+// branch-free (out-of-range chunks read a zero page; validity kept as a bit mask for the prologues).
+// K loop (IL, the default): tile t is multiplied while tile t+1 goes registers -> LDS and tile t+2 is
+// requested from memory, both in small pieces between the MFMA groups; one barrier per K-tile in the
+// middle of the iteration (see the loop). The plain three-phase loop (loads | MFMA block | ds_write +
+// addresses) is kept behind DMX_IGEMM_IL=0 for A/B measurements. Prologue, epilogue, the linear-layer
+// addressing mode and the loop kind are template parameters (one specialised kernel per combination the
+// plan emits).
 //
 // Alignment contract (checked by the host, dmx_ctx_create): every float4 staging chunk is
 // either entirely inside or entirely outside the valid input, and 16-byte aligned:
