@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
         const int p0 = st.p0, p1 = st.p1;
         const unsigned b = st.b;
         float s = 0.f, ss = 0.f;
-        if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY)
+        if (EPI == EPI_LINEAR || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
         {
             // no residual operand here (launch_dgemm refuses shapes that carry one): a load issued in the
             // epilogue would have to be waited for with vmcnt(0), i.e. behind the whole prefetched stage
@@ -285,8 +285,23 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
                             v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
                         *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
                     }
-                    s += (v.x + v.y) + (v.z + v.w);
-                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    if (EPI == EPI_STATS_FACT)
+                    {
+                        const int hid = p.Cout; // factorised statistics, see plan.h
+                        const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                            const int nn = n + r;
+                            ss += nn < hid ? vr[r] * vr[r] : (nn == hid + 1 ? 2.0f * vr[r] : 0.f);
+                            s += nn == hid ? vr[r] : 0.f;
+                        }
+                    }
+                    else
+                    {
+                        s += (v.x + v.y) + (v.z + v.w);
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
                 }
             }
             if (p.rowstat)
@@ -463,6 +478,8 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
         DMX_D(1, 3, 96, PRO_NONE, EPI_LINEAR, 1)
         // DConv k2 / k3: hidden 8 (C=48) / 12 (C=96) -> 2C, statistics / final
         DMX_D(6, 1, 8, PRO_GN_GELU, EPI_STATS_ONLY, 2)
+        DMX_D(1, 1, 8, PRO_GN_GELU, EPI_STATS_FACT, 0)
+        DMX_D(1, 1, 12, PRO_GN_GELU, EPI_STATS_FACT, 0)
         DMX_D(6, 1, 8, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0)
         DMX_D(12, 1, 12, PRO_GN_GELU, EPI_STATS_ONLY, 0)
         DMX_D(12, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1)

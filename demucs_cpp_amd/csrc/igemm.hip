@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
 #pragma unroll
         for (int j = 0; j < WNF; ++j)
             resv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
+        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
         {
             if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
             {
@@ -616,8 +616,25 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
                                         resv[j].w + v.w * scalev[j].w);
                         *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
                     }
-                    s += (v.x + v.y) + (v.z + v.w);
-                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    if (EPI == EPI_STATS_FACT)
+                    {
+                        // factorised statistics (plan.h): columns < hid are L a (squares), column hid is the row
+                        // sum of the full product, column hid+1 half of the remaining second-moment terms
+                        const int hid = p.Cout;
+                        const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                            const int nn = n + r;
+                            ss += nn < hid ? vr[r] * vr[r] : (nn == hid + 1 ? 2.0f * vr[r] : 0.f);
+                            s += nn == hid ? vr[r] : 0.f;
+                        }
+                    }
+                    else
+                    {
+                        s += (v.x + v.y) + (v.z + v.w);
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
                 }
             }
             if (wantStats)
@@ -728,7 +745,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
                 }
         }
     }
-    if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY)
+    if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
         if (wantStats)
         {
             __syncthreads();
@@ -827,6 +844,9 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(3, 4, 1, 2, 3, DMX_SMALL_KS, PRO_AFFINE, EPI_LINEAR)
         // cfg 4: 256x16, cfg 5: 128x32, cfg 6: 128x64
         DMX_CASE(4, 4, 1, 4, 1, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(4, 4, 1, 4, 1, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
+        DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
+        DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
         DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
         DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)

@@ -184,6 +184,87 @@ struct Packer
                 }
             }
             vec_paired(d + "k2.b", s + "3.bias");
+            // k2f: statistics-only surrogate of k2 (EPI_STATS_FACT). GroupNorm(1, 2C) needs sum(y) and
+            // sum(y^2) of y = W h + b per row; sum(y^2) = h^T (W^T W) h + 2 (W^T b).h + sum(b^2), so a factor
+            // L with L^T L = W^T W (from the symmetric eigen-decomposition, exact for rank-deficient W too)
+            // turns the 2C-column product into a (C/8 + 2)-column one. Everything in double, stored fp32.
+            {
+                const Raw &r = get(s + "3.weight");
+                const Raw &rb = get(s + "3.bias");
+                const int N = 2 * C, Kp = rup(C8p, 16), Nf = C8p + 2, Nfp = rup(Nf, 16);
+                std::vector<double> Am((size_t)C8 * C8, 0.0), u((size_t)C8, 0.0), v((size_t)C8, 0.0);
+                double sb = 0.0, sb2 = 0.0;
+                for (int n = 0; n < N; ++n)
+                {
+                    const double bn = rb.d[(size_t)n];
+                    sb += bn;
+                    sb2 += bn * bn;
+                    for (int k = 0; k < C8; ++k)
+                    {
+                        const double wk = r.d[(size_t)((i64)n * C8 + k)];
+                        u[(size_t)k] += wk;
+                        v[(size_t)k] += wk * bn;
+                        for (int l = 0; l < C8; ++l)
+                            Am[(size_t)k * C8 + l] += wk * (double)r.d[(size_t)((i64)n * C8 + l)];
+                    }
+                }
+                // cyclic Jacobi: Am -> diag(lambda), Q accumulates the rotations (columns = eigenvectors)
+                std::vector<double> Q((size_t)C8 * C8, 0.0);
+                for (int k = 0; k < C8; ++k)
+                    Q[(size_t)k * C8 + k] = 1.0;
+                for (int sweep = 0; sweep < 60; ++sweep)
+                {
+                    double off = 0.0;
+                    for (int a = 0; a < C8; ++a)
+                        for (int b2 = a + 1; b2 < C8; ++b2)
+                            off += Am[(size_t)a * C8 + b2] * Am[(size_t)a * C8 + b2];
+                    if (off < 1e-30)
+                        break;
+                    for (int a = 0; a < C8; ++a)
+                        for (int b2 = a + 1; b2 < C8; ++b2)
+                        {
+                            const double apq = Am[(size_t)a * C8 + b2];
+                            if (std::fabs(apq) < 1e-300)
+                                continue;
+                            const double theta = (Am[(size_t)b2 * C8 + b2] - Am[(size_t)a * C8 + a]) / (2.0 * apq);
+                            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                            for (int k = 0; k < C8; ++k)
+                            {
+                                const double akp = Am[(size_t)k * C8 + a], akq = Am[(size_t)k * C8 + b2];
+                                Am[(size_t)k * C8 + a] = c * akp - sn * akq;
+                                Am[(size_t)k * C8 + b2] = sn * akp + c * akq;
+                            }
+                            for (int k = 0; k < C8; ++k)
+                            {
+                                const double apk = Am[(size_t)a * C8 + k], aqk = Am[(size_t)b2 * C8 + k];
+                                Am[(size_t)a * C8 + k] = c * apk - sn * aqk;
+                                Am[(size_t)b2 * C8 + k] = sn * apk + c * aqk;
+                            }
+                            for (int k = 0; k < C8; ++k)
+                            {
+                                const double qkp = Q[(size_t)k * C8 + a], qkq = Q[(size_t)k * C8 + b2];
+                                Q[(size_t)k * C8 + a] = c * qkp - sn * qkq;
+                                Q[(size_t)k * C8 + b2] = sn * qkp + c * qkq;
+                            }
+                        }
+                }
+                float *wf = alloc(d + "k2f.Wt", (i64)Nfp * Kp);
+                float *bf = alloc(d + "k2f.b", Nfp);
+                for (int k = 0; k < C8; ++k) // row k of L = sqrt(lambda_k) * (eigenvector k)^T
+                {
+                    const double lam = std::max(Am[(size_t)k * C8 + k], 0.0), sq = std::sqrt(lam);
+                    for (int l = 0; l < C8; ++l)
+                        wf[(i64)k * Kp + l] = (float)(sq * Q[(size_t)l * C8 + k]);
+                }
+                for (int l = 0; l < C8; ++l)
+                {
+                    wf[(i64)C8p * Kp + l] = (float)u[(size_t)l];
+                    wf[(i64)(C8p + 1) * Kp + l] = (float)v[(size_t)l];
+                }
+                bf[C8p] = (float)sb;
+                bf[C8p + 1] = (float)(0.5 * sb2);
+            }
             vec_paired(d + "gn2.w", s + "4.weight");
             vec_paired(d + "gn2.b", s + "4.bias");
             vec(d + "scale", s + "6.scale", C);

@@ -68,6 +68,8 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi)
         1 * 1000000 + 3 * 100000 + 48 * 100 + PRO_NONE * 10 + EPI_LINEAR,
         1 * 1000000 + 3 * 100000 + 96 * 100 + PRO_NONE * 10 + EPI_LINEAR,
         6 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_STATS_ONLY,
+        1 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_STATS_FACT,
+        1 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_STATS_FACT,
         6 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
         12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_STATS_ONLY,
         12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
@@ -218,9 +220,17 @@ struct Builder
             h.epi = EPI_STATS_ONLY;
             h.y = -1, h.ldy = 0;
             h.rowstat = rs;
-            finish(h, true);
-            push_gemm(nm + ".k2", stream, h);
-            push_reduce(nm + ".r2", stream, rs, st2, B, (int)rows, h.NB, G0, (double)2 * C * P1 * (G0 > 1 ? 1 : P0), MODE_RSTD);
+            finish(h, true); // tile choice of the full product: inherited by K3 below
+            {
+                // statistics through the factorised weights (EPI_STATS_FACT): C/8 + 2 columns instead of 2C
+                IGemm f = h;
+                f.w_w = W(w + "k2f.Wt"), f.bias_w = W(w + "k2f.b");
+                f.N = C8p + 2, f.Cout = C8p;
+                f.epi = EPI_STATS_FACT;
+                finish(f, false);
+                push_gemm(nm + ".k2", stream, f);
+            }
+            push_reduce(nm + ".r2", stream, rs, st2, B, (int)rows, 1, G0, (double)2 * C * P1 * (G0 > 1 ? 1 : P0), MODE_RSTD);
             // K3: recompute, GroupNorm(1,2C) + GLU + LayerScale + residual  layers.cpp:240-253 / 348-374
             IGemm k = h;
             k.epi = EPI_GN_GLU_SCALE_RES;

@@ -55,6 +55,10 @@ enum Epilogue
     EPI_GN_GLU_SCALE_RES = 3,  // paired cols after GroupNorm: v = res + scale[c]*glu(gn(a),gn(b))
     EPI_STATS_ONLY = 4,        // row statistics of (acc+bias) only, nothing stored
     EPI_TRCONV = 5,            // n=(r,co): j = 4*p0 + r - 2; store [(b,p1,j)][co]; act; += res
+    EPI_STATS_FACT = 6,        // row statistics of a (N x K) linear map y = W a + b WITHOUT forming y: the weights
+                               // are the factor [L; u; v] (hid = Cout rows of L with L^T L = W^T W, u = W^T 1,
+                               // v = W^T b; bias = [0.., sum b, sum b^2 / 2]), so with z = acc + bias:
+                               //   sum_n y_n   = z[hid]          sum_n y_n^2 = sum_{k<hid} z[k]^2 + 2 z[hid+1]
 };
 
 // Statistics records are 4 floats: {mean, scale, std, 0}; scale is rstd = 1/sqrt(var+eps)

@@ -164,6 +164,16 @@ struct Interp
                     float s = 0.f, ss = 0.f;
                     for (int n = nb * BN; n < std::min(g.N, (nb + 1) * BN); ++n)
                     {
+                        if (g.epi == EPI_STATS_FACT) // factorised statistics: roles of the columns, plan.h
+                        {
+                            if (n < g.Cout)
+                                ss += v[(size_t)n] * v[(size_t)n];
+                            else if (n == g.Cout)
+                                s += v[(size_t)n];
+                            else if (n == g.Cout + 1)
+                                ss += 2.0f * v[(size_t)n];
+                            continue;
+                        }
                         s += v[(size_t)n];
                         ss += v[(size_t)n] * v[(size_t)n];
                     }
