@@ -19,31 +19,54 @@ namespace dmx
 #define FFT_N 4096
 #define FFT_LOG 12
 
-// In-LDS Stockham radix-2 DIF FFT of FFT_N complex points. After the call the result is
-// in `a` (12 stages = even). sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse.
-// tw[k] = exp(-2 pi i k / 4096), k < 2048.
+// In-LDS Stockham radix-4 DIF FFT of FFT_N = 4^6 complex points (6 autosort stages, one barrier each;
+// the radix-2 version needed 12). After the call the result is in `a` (6 stages = even).
+// sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse. tw[k] = exp(-2 pi i k / 4096), k < 2048;
+// exponents in [2048, 3072) use w^(k) = -w^(k - 2048).
+// Stage with stride s (= 4^st), sub-transform length n = N/s, quarter m = n/4, p < m, q < s:
+//   y[q + s (4p + k)] = w_n^(p k) * sum_j omega_4^(j k) x[q + s (p + j m)],  omega_4 = -i (forward) / +i (inverse)
+template <int SIGN>
+__device__ __forceinline__ float2 fft_tw(const float2 *__restrict__ tw, int idx)
+{
+    float2 w = tw[idx & 2047];
+    if (idx & 2048)
+        w = make_float2(-w.x, -w.y);
+    if (SIGN > 0)
+        w.y = -w.y;
+    return w;
+}
+__device__ __forceinline__ float2 cmul(const float2 a, const float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+
 template <int SIGN>
 __device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__restrict__ tw, int tid)
 {
     float2 *x = a, *y = b;
 #pragma unroll 1
-    for (int st = 0; st < FFT_LOG; ++st)
+    for (int st = 0; st < FFT_LOG; st += 2)
     {
-        const int s = 1 << st;          // stride
-        const int m = (FFT_N >> st) >> 1; // half length of the sub-transform
+        const int s = 1 << st;        // stride
+        const int m = FFT_N >> (st + 2); // quarter length of the sub-transform
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
         {
-            const int j = tid + i * 256; // butterfly index 0..2047
+            const int j = tid + i * 256; // butterfly index 0..1023
             const int p = j >> st, q = j & (s - 1);
-            const float2 u = x[q + s * p];
-            const float2 v = x[q + s * (p + m)];
-            float2 w = tw[p << st];
-            if (SIGN > 0)
-                w.y = -w.y;
-            const float2 d = make_float2(u.x - v.x, u.y - v.y);
-            y[q + s * (2 * p)] = make_float2(u.x + v.x, u.y + v.y);
-            y[q + s * (2 * p + 1)] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+            const float2 a0 = x[q + s * p];
+            const float2 a1 = x[q + s * (p + m)];
+            const float2 a2 = x[q + s * (p + 2 * m)];
+            const float2 a3 = x[q + s * (p + 3 * m)];
+            const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+            const float2 b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+            const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+            // (a1 - a3) * (-i) forward, * (+i) inverse
+            const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
+            const float2 b3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+            const int e = p << st; // twiddle exponent of w_N for k = 1
+            const int o = q + s * (4 * p);
+            y[o] = make_float2(b0.x + b2.x, b0.y + b2.y);
+            y[o + s] = cmul(make_float2(b1.x + b3.x, b1.y + b3.y), fft_tw<SIGN>(tw, e));
+            y[o + 2 * s] = cmul(make_float2(b0.x - b2.x, b0.y - b2.y), fft_tw<SIGN>(tw, 2 * e));
+            y[o + 3 * s] = cmul(make_float2(b1.x - b3.x, b1.y - b3.y), fft_tw<SIGN>(tw, 3 * e));
         }
         __syncthreads();
         float2 *t = x;
