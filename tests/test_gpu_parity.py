@@ -350,3 +350,26 @@ def test_stream_schedule_does_not_change_a_bit(dmx, tmp_models, monkeypatch):
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     m.close()
+
+
+@pytest.mark.parametrize("ns,seg,B", [(4, 6000, 12), (6, 4096, 5), (4, 4098, 2)])
+def test_bench_batch_and_awkward_lengths_equal_singles(ns, seg, B, dmx, tmp_models):
+    """The bench's batch of 12 (single-stream mode), the shortest supported segment and an awkward length:
+    every segment of a batch equals the same segment run alone, bit for bit, and matches the oracle."""
+    import torch
+    rng = np.random.default_rng(100 + seg + B)
+    mixes = (0.1 * rng.standard_normal((B, 2, seg))).astype(np.float32)
+    m = dmx.Model(tmp_models[ns]); ctx = dmx.Context(m, seg, B); c1 = dmx.Context(m, seg, 1)
+    d_mix = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).cuda()
+    d_out = torch.zeros((B, ns, 2, seg), device="cuda")
+    torch.cuda.synchronize()
+    ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.isfinite(got).all()
+    for b in (0, B // 2, B - 1):
+        assert np.array_equal(got[b], c1.segment(mixes[b]))
+    om = orc.OracleModel(tmp_models[ns])
+    ref = om.segment(mixes[B - 1])
+    assert np.abs(got[B - 1] - ref).max() <= TOL * np.abs(ref).max()
+    om.close(); ctx.close(); c1.close(); m.close()
