@@ -61,6 +61,11 @@ struct dmx_ctx
     std::vector<hipEvent_t> events; // one per op index (created on first use), + fork / join
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     int lastBatch = 0;
+    // caller buffers the plan reads its input from / writes its output to directly (device entry point):
+    // the arena regions [mixOff, +mixLen) and [outOff, +outLen) are redirected while they are set
+    const float *extMix = nullptr;
+    float *extOut = nullptr;
+    i64 redirMixOff = 0, redirMixLen = 0, redirOutOff = 0, redirOutLen = 0;
     // track-level scratch
     double *dPartials = nullptr;
     int *dSegIdx = nullptr;
@@ -251,7 +256,15 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff
 {
     float *A = c->dA;
     const float *W = c->m->dW;
-    auto a = [&](i64 off) -> float * { return off >= 0 ? A + off : nullptr; };
+    auto a = [&](i64 off) -> float * {
+        if (off < 0)
+            return nullptr;
+        if (c->extMix && off >= c->redirMixOff && off < c->redirMixOff + c->redirMixLen)
+            return const_cast<float *>(c->extMix) + (off - c->redirMixOff); // only ever read
+        if (c->extOut && off >= c->redirOutOff && off < c->redirOutOff + c->redirOutLen)
+            return c->extOut + (off - c->redirOutOff);
+        return A + off;
+    };
     auto w = [&](i64 off) -> const float * { return off >= 0 ? W + off : nullptr; };
     switch (op.kind)
     {
@@ -382,14 +395,14 @@ extern "C" int dmx_segment_infer_device(dmx_ctx *c, const float *d_mix, float *d
     HIPCHK(hipSetDevice(c->m->device));
     Plan *p = get_plan(c, batch);
     const int S = c->m->pm.n_sources;
-    HIPCHK(hipMemcpyAsync(c->dA + p->mixOff, d_mix, sizeof(float) * (size_t)batch * c->seg * 2, hipMemcpyDeviceToDevice,
-                          c->stream));
+    // the kernels read the caller's mix and write the caller's output directly (no staging copies):
+    // both buffers have exactly the layout of the arena regions they stand in for
+    c->extMix = d_mix, c->extOut = d_out;
+    c->redirMixOff = p->mixOff, c->redirMixLen = (i64)batch * c->seg * 2;
+    c->redirOutOff = p->outOff, c->redirOutLen = (i64)batch * S * 2 * c->seg;
     int rc = run_plan(c, batch);
-    if (rc)
-        return rc;
-    HIPCHK(hipMemcpyAsync(d_out, c->dA + p->outOff, sizeof(float) * (size_t)batch * S * 2 * c->seg, hipMemcpyDeviceToDevice,
-                          c->stream));
-    return DMX_OK;
+    c->extMix = nullptr, c->extOut = nullptr;
+    return rc;
 }
 
 extern "C" int dmx_segment_infer(dmx_ctx *c, const float *mix, float *out, int layout)

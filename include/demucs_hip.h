@@ -89,7 +89,8 @@ extern "C"
     int dmx_segment_infer(dmx_ctx *c, const float *mix, float *out, int layout);
 
     /* Same on device memory, `batch` (<= max_batch) segments, asynchronous on the
-     * context's stream (pair with dmx_ctx_synchronize):
+     * context's stream (pair with dmx_ctx_synchronize). The kernels read d_mix and write d_out
+     * directly (no staging copy): both must be 16-byte aligned and stay valid until the work completes:
      *   d_mix : [batch][segment_samples][2] interleaved, d_out : [batch][S][2][segment_samples] planar. */
     int dmx_segment_infer_device(dmx_ctx *c, const float *d_mix, float *d_out, int batch);
 
