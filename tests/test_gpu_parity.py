@@ -373,3 +373,28 @@ def test_bench_batch_and_awkward_lengths_equal_singles(ns, seg, B, dmx, tmp_mode
     ref = om.segment(mixes[B - 1])
     assert np.abs(got[B - 1] - ref).max() <= TOL * np.abs(ref).max()
     om.close(); ctx.close(); c1.close(); m.close()
+
+
+def test_cli_mono_input_is_duplicated_to_stereo(dmx, tmp_models, golden_dir, tmp_path):
+    """Mono WAVs are duplicated to both channels before inference (/root/reference/cli-apps/demucs.cpp:56-64);
+    run on the reference's own mono fixture (test/data/gspi_mono.wav, 262144 samples, PCM16)."""
+    import subprocess
+    from wavio import read_wav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cli", "demucs.cpp.main")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    wav = os.path.join(golden_dir, "gspi_mono.wav")
+    rate, mono = read_wav(wav)
+    assert rate == 44100 and mono.shape[0] == 1
+    out_dir = tmp_path / "stems"
+    env = dict(os.environ, DMX_SHIFT_OFFSET="7", DMX_BATCH="1")
+    r = subprocess.run([exe, tmp_models[4], wav, str(out_dir)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    audio = np.repeat(mono, 2, axis=0)
+    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 1)
+    ref = ctx.track(audio, 7)
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        _, stem = read_wav(str(out_dir / f"target_{i}_{name}.wav"))
+        assert stem.shape == audio.shape and np.array_equal(stem, ref[i])
+    ctx.close(); m.close()
