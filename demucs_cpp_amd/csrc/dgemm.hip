@@ -421,27 +421,6 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
     }
 }
 
-static FastDiv make_fastdiv(unsigned d)
-{
-    FastDiv f;
-    f.magic = 0;
-    f.shift = 0;
-    if (d == 0)
-        d = 1;
-    if ((d & (d - 1)) == 0)
-    {
-        while ((1u << f.shift) < d)
-            ++f.shift;
-        return f;
-    }
-    unsigned s = 0;
-    while ((1ull << s) < d)
-        ++s;
-    f.magic = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d); // exact for n < 2^31
-    f.shift = s - 1;
-    return f;
-}
-
 #ifndef DMX_DG_PIPE
 #define DMX_DG_PIPE -1 // -1: per-shape choice of the launch table; 0/1/2 force one pipeline (experiments)
 #endif

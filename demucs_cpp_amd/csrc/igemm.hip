@@ -109,11 +109,14 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
         int4 ri = make_int4(0, 0, 0, -1);
         if (m < p.M)
         {
-            const int p0 = (int)(m % p.P0);
-            const i64 t = m / p.P0;
-            const int p1 = (int)(t % p.P1);
-            const int b = (int)(t / p.P1);
-            ri = make_int4(b, p1, p0, b * p.G0 + (p.G0 > 1 ? p0 : 0));
+            // magic-number divisions (three 64-bit software divides per row were a visible part of the
+            // per-tile prologue)
+            const unsigned mu = (unsigned)m;
+            const unsigned t = p.dP0.magic ? (__umulhi(mu, p.dP0.magic) >> p.dP0.shift) : (mu >> p.dP0.shift);
+            const int p0 = (int)(mu - t * (unsigned)p.P0);
+            const unsigned b = p.dP1.magic ? (__umulhi(t, p.dP1.magic) >> p.dP1.shift) : (t >> p.dP1.shift);
+            const int p1 = (int)(t - b * (unsigned)p.P1);
+            ri = make_int4((int)b, p1, p0, (int)b * p.G0 + (p.G0 > 1 ? p0 : 0));
         }
         rowinfo[r] = ri;
     }
@@ -786,6 +789,7 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
     a.tilesM = (unsigned)((a.M + BM - 1) / BM);
     a.tilesN = (unsigned)((a.N + BN - 1) / BN);
     a.xcdMap = xcdMap;
+    a.dP0 = make_fastdiv((unsigned)a.P0), a.dP1 = make_fastdiv((unsigned)a.P1);
     const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
     static const int linOn = getenv("DMX_IGEMM_LIN") ? atoi(getenv("DMX_IGEMM_LIN")) : 1;
     static const int ilOn = getenv("DMX_IGEMM_IL") ? atoi(getenv("DMX_IGEMM_IL")) : 1;
@@ -812,6 +816,8 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
 // interp_combos). key = cfg*100 + pro*10 + epi.
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
 {
+    if (a.M >= (1ll << 31) - 256)
+        return -1; // 32-bit row arithmetic in the kernel prologue
 #define DMX_CASE(cfgid, WM_, WN_, MF, NF, KS, PRO, EPI) \
     case (cfgid * 100 + PRO * 10 + EPI):                \
         if (!dry)                                       \

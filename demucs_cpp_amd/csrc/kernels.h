@@ -7,6 +7,31 @@
 namespace dmx
 {
 
+struct FastDiv // n / d for n < 2^31: magic == 0 ? n >> shift : umulhi(n, magic) >> shift
+{
+    unsigned magic, shift;
+};
+inline FastDiv make_fastdiv(unsigned d)
+{
+    FastDiv f;
+    f.magic = 0;
+    f.shift = 0;
+    if (d == 0)
+        d = 1;
+    if ((d & (d - 1)) == 0)
+    {
+        while ((1u << f.shift) < d)
+            ++f.shift;
+        return f;
+    }
+    unsigned s = 0;
+    while ((1ull << s) < d)
+        ++s;
+    f.magic = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d); // exact for n < 2^31
+    f.shift = s - 1;
+    return f;
+}
+
 struct GemmArgs
 {
     const float *X;
@@ -33,13 +58,10 @@ struct GemmArgs
     unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
     // launch geometry (filled by launch_igemm): 1-D grid, workgroup id -> (row tile, column tile)
     unsigned tilesM, tilesN;
+    FastDiv dP0, dP1; // row index m -> (b, p1, p0) without 64-bit divisions (M < 2^31 is checked by the launcher)
     int xcdMap; // 1: XCD-aware mapping (all column tiles of a row tile on ONE XCD, adjacent in dispatch order)
 };
 
-struct FastDiv // n / d for n < 2^31: magic == 0 ? n >> shift : umulhi(n, magic) >> shift
-{
-    unsigned magic, shift;
-};
 // direct (register-resident weights, no LDS) kernels for the HBM-bound layers; -1 if the shape is
 // not in their table
 int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
