@@ -45,11 +45,12 @@ PEAK_TFLOPS_FP32_MFMA = 157.3
 MODEL_FLOPS_4S = 340.2e9  # algorithmic FLOPs per segment (SURVEY.md §8d / BASELINE.md §3)
 
 
-def pmc_traffic(kernel_class):
+def pmc_traffic(kernel_class, batch):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes
     (profiles/rNN_traffic.json, written by tools/traffic_json.py from separate FETCH_SIZE and
-    WRITE_SIZE passes over `bench.py --batch 12`; gfx950 corrections applied there). The counters
-    cannot be collected from inside this process, so the newest committed pass is quoted."""
+    WRITE_SIZE passes over this same workload; gfx950 corrections applied there). The counters cannot be
+    collected from inside this process, so the newest committed pass is quoted - only if it was taken at
+    the same batch size."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
@@ -58,6 +59,8 @@ def pmc_traffic(kernel_class):
     try:
         with open(files[-1]) as f:
             d = json.load(f)
+        if int(d.get("batch", -1)) != batch:
+            return None, None
         return d["classes"][kernel_class]["traffic_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
     except Exception:
         return None, None
@@ -68,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "12")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "24")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
@@ -260,7 +263,7 @@ def main():
         kname, (ms, fl, by, cnt) = dom
         tot_ms = sum(v[0] for v in by_kernel.values())
         achieved = fl / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(kname) if B == 12 else (None, None)
+        traffic, traffic_src = pmc_traffic(kname, B)
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": traffic,

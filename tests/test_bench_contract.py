@@ -20,7 +20,7 @@ def test_bench_refuses_without_gpu():
 
 
 def test_committed_bench_line_schema():
-    path = os.path.join(ROOT, "profiles", "r01_bench_b12.json")
+    path = os.path.join(ROOT, "profiles", "r01_bench_b24.json")
     d = json.loads(open(path).read())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -37,6 +37,6 @@ def test_committed_bench_line_schema():
     assert c["kind"] == "port"
     # the rocprofv3 average of the dominant kernel agrees with the live measurement (within 5 %)
     import csv
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_b12_by_class.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_b24_by_class.csv"))))
     row = next(x for x in rows if x["kernel"] == r["kernel"])
     assert abs(float(row["avg_us"]) / 1e3 - r["avg_launch_ms"]) / r["avg_launch_ms"] < 0.05

@@ -2,7 +2,7 @@
 # Effective shader clock per kernel class under the bench workload: GRBM_GUI_ACTIVE (cycles the GPU
 # was busy during the dispatch) / kernel duration (MI355X_MICROARCH.md §DVFS give-back). Own PMC pass.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-B=${1:-12}
+B=${1:-24}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single"

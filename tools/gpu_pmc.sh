@@ -2,7 +2,7 @@
 # PMC passes over the bench workload (each its own run; never combined with other traces).
 #   tools/gpu_pmc.sh [batch]     -> gpurun_out/pmc/pass_{A,B,C,D}.csv (+ per class) and traffic.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
-B=${1:-12}
+B=${1:-24}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single"
@@ -18,5 +18,5 @@ for x in A B C D; do
   python $R/tools/pmc_summary.py $f --class > $R/gpurun_out/pmc/pass_${x}_class.csv 2>&1
   head -8 $R/gpurun_out/pmc/pass_${x}_class.csv
 done
-python $R/tools/traffic_json.py $(find /tmp/pmcC -name "*.db" | head -1) $(find /tmp/pmcD -name "*.db" | head -1) > $R/gpurun_out/pmc/traffic.json
+python $R/tools/traffic_json.py $(find /tmp/pmcC -name "*.db" | head -1) $(find /tmp/pmcD -name "*.db" | head -1) $B > $R/gpurun_out/pmc/traffic.json
 cat $R/gpurun_out/pmc/traffic.json | head -30

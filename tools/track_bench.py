@@ -25,7 +25,7 @@ SEG = 343980
 
 def main():
     ns = int(os.environ.get("NS", "4"))
-    mb = int(os.environ.get("MAXBATCH", "12"))
+    mb = int(os.environ.get("MAXBATCH", "24"))
     path = f"/tmp/track_bench_{ns}s.bin"
     write_synthetic_model(path, ns, 0 if ns == 4 else 3)
     m = dmx.Model(path)

@@ -2,7 +2,7 @@
 """HBM traffic per kernel class and launch from two separate rocprofv3 PMC passes
 (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md §rocprofv3 PMC slots).
 
-  traffic_json.py fetch.db write.db > profiles/rNN_traffic.json
+  traffic_json.py fetch.db write.db <batch> > profiles/rNN_traffic.json
 
 Corrections (MI355X_MICROARCH.md §HBM): both counters are in KB; on gfx950 FETCH_SIZE counts the
 128-B requests of 16-B/lane coalesced reads at 64 B, so reads are doubled. Every kernel of this
@@ -16,8 +16,9 @@ from pmc_summary import aggregate  # noqa: E402
 
 fa, fc, _ = aggregate(sys.argv[1], True)
 wa, wc, _ = aggregate(sys.argv[2], True)
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 out = {"_note": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches; rocprofv3 --pmc, separate passes, "
-                "bench.py --batch 12", "classes": {}}
+                "bench.py --batch %d" % batch, "batch": batch, "classes": {}}
 for k in fa:
     if k not in wa:
         continue
