@@ -352,9 +352,9 @@ def test_stream_schedule_does_not_change_a_bit(dmx, tmp_models, monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("ns,seg,B", [(4, 6000, 12), (6, 4096, 5), (4, 4098, 2)])
+@pytest.mark.parametrize("ns,seg,B", [(4, 6000, 24), (4, 6000, 12), (6, 4096, 5), (4, 4098, 2)])
 def test_bench_batch_and_awkward_lengths_equal_singles(ns, seg, B, dmx, tmp_models):
-    """The bench's batch of 12 (single-stream mode), the shortest supported segment and an awkward length:
+    """The bench batches 24 and 12 (single-stream mode), the shortest supported segment and an awkward length:
     every segment of a batch equals the same segment run alone, bit for bit, and matches the oracle."""
     import torch
     rng = np.random.default_rng(100 + seg + B)
