@@ -70,7 +70,7 @@ struct demucs_model
     bool is_4sources = true;
     int device = 0;          // HIP device the weights live on (env DMX_DEVICE at load time)
     int shift_offset = -1;   // -1: rand() % 22050 like src/model_apply.cpp:114; else fixed
-    int max_batch = 4;       // segments in flight per context
+    int max_batch = 12;      // segments in flight per context (7.8 GB of arena; 3.4 ms per segment vs 4.1 at 4)
     dmx_model *handle = nullptr;
     mutable dmx_ctx *ctx = nullptr; // lazily created, reused across calls (one per model object)
     demucs_model() {}
