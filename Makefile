@@ -4,24 +4,24 @@ ARCH ?= gfx950
 CSRC := demucs_cpp_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB := demucs_cpp_amd/lib/libdemucs_hip.so
-OBJS := $(addprefix build/,igemm.o dgemm.o fft.o misc.o attention.o api.o plan.o model_pack.o)
+OBJS := $(addprefix build/,igemm.o dgemm.o fft.o misc.o attention.o api.o engine.o plan.o model_pack.o)
 
-all: $(LIB) cli oracle interp
+all: $(LIB) cli oracle interp harness
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/plan.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-build/%.o: $(CSRC)/%.cpp $(CSRC)/kernels.h $(CSRC)/plan.h include/demucs_hip.h
+build/%.o: $(CSRC)/%.cpp $(CSRC)/kernels.h $(CSRC)/plan.h $(CSRC)/api_internal.h include/demucs_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIB): $(OBJS)
 	@mkdir -p demucs_cpp_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -lpthread
 
 cli: cli/demucs.cpp.main cli/demucs_ft.cpp.main cli/demucs_mt.cpp.main cli/demucs_ft_mt.cpp.main
 cli/%.cpp.main: cli/%_main.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp demucs_cpp_amd/host/threaded_inference_hip.hpp cli/wav.hpp
-	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -Wl,-rpath,'$$ORIGIN/../demucs_cpp_amd/lib'
+	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../demucs_cpp_amd/lib'
 
 oracle:
 	$(MAKE) -C oracle
@@ -29,14 +29,23 @@ interp:
 	@mkdir -p tests/_build
 	g++ -O2 -march=native -fopenmp -std=c++17 -fPIC -shared -o tests/_build/libcpu_interp.so tests/cpu_interp.cpp
 
+# GPU test harnesses of the C++ shim (re-entrancy; Eigen-typed overloads against tests/eigen_stub, which is NOT Eigen)
+harness: tests/_build/shim_harness tests/_build/shim_harness_eigen
+tests/_build/shim_harness: tests/shim_harness.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp
+	@mkdir -p tests/_build
+	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../../demucs_cpp_amd/lib'
+tests/_build/shim_harness_eigen: tests/shim_harness.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp
+	@mkdir -p tests/_build
+	g++ -O2 -std=c++17 -DDEMUCSCPP_HIP_WITH_EIGEN -Itests/eigen_stub -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../../demucs_cpp_amd/lib'
+
 clean:
 	rm -rf build $(LIB) tests/_build cli/*.main
 	$(MAKE) -C oracle clean
-.PHONY: all cli oracle interp clean
+.PHONY: all cli oracle interp harness clean
 
 # experiment builds: make variant NAME=timing FLAGS="-DDMX_TIMING -DDMX_PIN_LOADS=1"
 variant:
 	@mkdir -p build/$(NAME)
 	for f in igemm dgemm fft misc attention; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
-	for f in api plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
+	for f in api engine plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so build/$(NAME)/*.o

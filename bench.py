@@ -15,8 +15,20 @@ hot path). The one real exchange step of the track path - gathering the per-segm
 to the root before overlap-add (north_star) - is part of every step when N > 1
 (RCCL gather over xGMI), followed by the root's triangle-weighted overlap-add of all N*batch
 segments (dmx_track_overlap_add_device); with N = 1 the overlap-add alone runs.
-value = audio seconds pushed through the hot path per wall second = N*batch*7.8*K / T, T = max
-over ranks of the barrier-bracketed wall time of the K timed steps.
+value = seconds of TRACK produced per wall second: the N*batch segments of a step are the consecutive
+overlapping segments of one stretch of a track (stride 257985 samples = 5.85 s of new audio per 7.8 s
+segment, src/model_apply.cpp:162), which the root overlap-adds into n_track = N*batch*257985 - 22050
+samples; value = n_track/44100 * K / T, T = max over ranks of the barrier-bracketed wall time of the K timed
+steps. (Round 1 counted the 7.8 s every segment PROCESSES; that figure stays in config.segment_seconds_per_s.)
+
+config also reports, measured in this same run:
+  track_4min_xRT      (N = 1) BASELINE configs[2] end to end through dmx_track_infer: host buffers in and
+                      out (PCIe inclusive: H2D of the 85 MB track, normalisation, 42 segments, overlap-add,
+                      D2H of the 339 MB stems), 240 s / wall;
+  track_strong_xRT    (every N) ONE such track with its 42 segments dealt over the N ranks (contiguous
+                      ranges), RCCL gather of the per-segment outputs to the root, root overlap-add, D2H on
+                      the root: strong scaling of a single track (<= 87.5 % at N = 8: 42 = 6+6+5*6);
+  single_segment_latency_ms  BASELINE configs[1] read literally (one segment per call, device resident).
 
 Extra objects on the JSON line:
   roofline     : dominant kernel (by device time) measured live with HIP events on the stream
@@ -75,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-track", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: TEST MODE ONLY - several ranks share GPU 0 and the gather goes through host memory, to "
                          "exercise the N > 1 control flow (double buffering, flush, overlap-add of all ranks' segments) on a "
@@ -249,6 +262,53 @@ def main():
         ctx.synchronize()
         single_ms = (time.perf_counter() - t1) / 10 * 1e3
 
+    # ---- BASELINE configs[2]: a 4-minute track end to end (host buffers in and out), and the same track
+    # strong-scaled over the ranks (segments dealt in contiguous ranges, RCCL gather, root overlap-add)
+    track_4min = None
+    track_strong = None
+    if not args.no_track:
+        n4 = 240 * 44100
+        g4 = torch.Generator(device="cpu").manual_seed(1)
+        audio_il = (0.1 * torch.randn((n4, 2), generator=g4))  # the same track on every rank
+        ctx.set_stream(None)
+        torch.cuda.synchronize()
+        if rank == 0 and world == 1:
+            a_planar = np.ascontiguousarray(audio_il.numpy().T)
+            res = np.zeros((S, 2, n4), np.float32)
+            ctx.track(a_planar[:, :3 * SEG], 4033)  # warm-up of the scratch buffers
+            ctx.track(a_planar, 4033, out=res)
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ctx.track(a_planar, 4033, out=res)
+                ts.append(time.perf_counter() - t1)
+            track_4min = {"xRT": round(240.0 / min(ts), 1), "wall_s": [round(t, 4) for t in ts], "segments": 42,
+                          "host_MB_in_out": round((a_planar.nbytes + res.nbytes) / 1e6, 1), "finite": bool(np.isfinite(res).all())}
+            del res
+        if not test_mode:
+            from demucs_cpp_amd.distributed import HipBackend, track_infer_sharded
+
+            be = HipBackend(ctx)
+            pinned = audio_il.pin_memory()
+            host_out = torch.empty((S, 2, n4), dtype=torch.float32).pin_memory() if rank == 0 else None
+            ts = []
+            for it in range(4):  # first pass = warm-up
+                fence()
+                t1 = time.perf_counter()
+                d_audio = pinned.to("cuda", non_blocking=True)
+                o = track_infer_sharded(be, d_audio, 4033, dist=dist, rank=rank, world=world)
+                if rank == 0:
+                    host_out.copy_(o, non_blocking=True)
+                fence()
+                ts.append(time.perf_counter() - t1)
+            tt = torch.tensor(ts[1:], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = float(tt.min().item())
+            track_strong = {"xRT": round(240.0 / best, 1), "wall_s": [round(float(t), 4) for t in tt.tolist()], "segments": 42,
+                            "ranks": world, "host_buffers": "pinned"}
+        ctx.set_stream(stream.cuda_stream)
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         prof = ctx.profile(B, 3)
@@ -293,7 +353,8 @@ def main():
         om.close()
 
     if rank == 0:
-        audio_s = nseg_total * SEG_SECONDS * args.steps
+        audio_s = n_track / 44100.0 * args.steps          # seconds of track produced
+        seg_s = nseg_total * SEG_SECONDS * args.steps        # seconds of audio processed (segments overlap by 25 %)
         line = {
             "metric": "audio-sec/s (xRT) htdemucs-4s 44.1kHz stereo, per-segment hot path",
             "value": round(audio_s / elapsed, 2),
@@ -308,9 +369,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "htdemucs-4s f16-weights, 343980-sample segments, fp32 MFMA compute, "
-                                   f"{B} segments/GPU/step resident in HBM + root overlap-add"
+                                   f"{B} consecutive overlapping segments/GPU/step resident in HBM + root overlap-add"
                                    + (" + RCCL gather to root" if world > 1 else ""),
+                       "value_counts": "seconds of track produced (5.85 s of new audio per 7.8 s segment, stride 257985)",
                        "segments_per_gpu_per_step": B, "segment_samples": SEG, "audio_seconds_per_segment": SEG_SECONDS,
+                       "segment_seconds_per_s": round(seg_s / elapsed, 2),
+                       "track_4min_xRT": track_4min, "track_strong_xRT": track_strong,
                        "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),

@@ -4,6 +4,7 @@
 // mono (duplicated to both channels, demucs.cpp:56-64) or stereo only; writes stereo
 // float32 like the reference (PCM_FLT, demucs.cpp:100-102).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -56,7 +57,8 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
             memcpy(&nch, &b[pos + 10], 2);
             memcpy(&rate, &b[pos + 12], 4);
             memcpy(&bits, &b[pos + 22], 2);
-            if (tag == 0xFFFE && sz >= 26) // WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first 2 bytes
+            // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID's first 2 bytes, if the fmt chunk really holds them
+            if (tag == 0xFFFE && sz >= 26 && pos + 8 + 26 <= b.size())
                 memcpy(&tag, &b[pos + 8 + 24], 2);
         }
         else if (memcmp(&b[pos], "data", 4) == 0)
@@ -80,6 +82,12 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
     if (nch != 1 && nch != 2)
     {
         std::cerr << "[ERROR] demucs.cpp only supports mono and stereo audio" << std::endl; // :42-48
+        return false;
+    }
+    // validate the encoding BEFORE bits / 8 is used as a divisor (a 4-bit ADPCM file must not die with SIGFPE)
+    if (!((tag == 3 && bits == 32) || (tag == 1 && (bits == 16 || bits == 24 || bits == 32))))
+    {
+        std::cerr << "[ERROR] unsupported wav encoding (tag " << tag << ", " << bits << " bits)" << std::endl;
         return false;
     }
     const size_t bps = bits / 8;
@@ -112,11 +120,6 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         }
         return 0.0f;
     };
-    if (!((tag == 3 && bits == 32) || (tag == 1 && (bits == 16 || bits == 24 || bits == 32))))
-    {
-        std::cerr << "[ERROR] unsupported wav encoding (tag " << tag << ", " << bits << " bits)" << std::endl;
-        return false;
-    }
     std::cout << "Input samples: " << N << std::endl;
     std::cout << "Length in seconds: " << (double)N / rate << std::endl;
     std::cout << "Number of channels: " << nch << std::endl;

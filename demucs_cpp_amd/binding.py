@@ -28,8 +28,12 @@ EXPORTS = [
     "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_ctx_set_stream", "dmx_segment_infer",
     "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
-    "dmx_debug_profile", "dmx_debug_igemm_timing",
+    "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model",
+    "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
+    "dmx_engine_transport", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2
 
 _lib = None
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_float, ctypes.c_char_p, ctypes.c_void_p)
@@ -82,6 +86,14 @@ def lib():
         L.dmx_debug_n_ops.argtypes = [vp]
         L.dmx_debug_profile.argtypes = [vp, ci, ci, ctypes.c_char_p, ci]
         L.dmx_debug_igemm_timing.argtypes = [vp, ci, ctypes.c_char_p, fp]
+        L.dmx_ctx_set_model.argtypes = [vp, vp]
+        L.dmx_engine_create.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, ctypes.POINTER(ci), ci, ci, ci, ctypes.POINTER(vp)]
+        L.dmx_engine_free.argtypes = [vp]
+        for f in ("dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources", "dmx_engine_transport"):
+            getattr(L, f).argtypes = [vp]
+        L.dmx_engine_root_ctx.argtypes = [vp, ci]
+        L.dmx_engine_root_ctx.restype = vp
+        L.dmx_engine_track_infer.argtypes = [vp, fp, i64, ctypes.POINTER(ci), fp, ci, vp, vp]
         _lib = L
     return _lib
 
@@ -165,11 +177,13 @@ class Context:
         _chk(lib().dmx_segment_infer(self.h, mix.ctypes.data, out.ctypes.data, LAYOUT_EIGEN))
         return out
 
-    def track(self, audio: np.ndarray, shift_offset: int, progress=None) -> np.ndarray:
-        """audio (2, n) planar -> (S, 2, n); demucscpp::demucs_inference."""
+    def track(self, audio: np.ndarray, shift_offset: int, progress=None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """audio (2, n) planar -> (S, 2, n); demucscpp::demucs_inference. `out`: reuse a result buffer."""
         audio = np.ascontiguousarray(audio, np.float32)
         n = audio.shape[1]
-        out = np.zeros((self.S, 2, n), np.float32)
+        if out is None:
+            out = np.zeros((self.S, 2, n), np.float32)
+        assert out.shape == (self.S, 2, n) and out.dtype == np.float32 and out.flags.c_contiguous
         cb = PROGRESS_FN(lambda p, m, u: progress(p, m.decode())) if progress else None
         cbp = ctypes.cast(cb, ctypes.c_void_p) if cb else None
         _chk(lib().dmx_track_infer(self.h, audio.ctypes.data, n, shift_offset, out.ctypes.data, LAYOUT_PLANAR, cbp, None))
@@ -220,6 +234,61 @@ class Context:
             nm, k, ms, fl, by = ln.split("\t")
             rows.append((nm, k, float(ms), float(fl), float(by)))
         return rows
+
+
+def engine_partition(n_segments, n_devices):
+    """[(device l) -> [(model, g0, g1), ...]]: the contiguous balanced dealing of csrc/engine.cpp."""
+    M = len(n_segments)
+    ns = (ctypes.c_int * M)(*n_segments)
+    out = (ctypes.c_int * (n_devices * M * 2))()
+    L = lib()
+    L.dmx_engine_partition.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    _chk(L.dmx_engine_partition(ns, M, n_devices, out))
+    res = []
+    for l in range(n_devices):
+        res.append([(m, out[(l * M + m) * 2], out[(l * M + m) * 2 + 1]) for m in range(M)
+                    if out[(l * M + m) * 2 + 1] > out[(l * M + m) * 2]])
+    return res
+
+
+class Engine:
+    """Several GPUs and / or a bag of models in one process (csrc/engine.cpp): demucs_inference with the
+    (model, segment) items sharded over `devices`; `devices` may repeat an id (logical devices on one GPU)."""
+
+    def __init__(self, model_files, devices=None, max_batch: int = 4, transport: int = TRANSPORT_AUTO):
+        files = (ctypes.c_char_p * len(model_files))(*[f.encode() for f in model_files])
+        devs = (ctypes.c_int * len(devices))(*devices) if devices else None
+        self.h = ctypes.c_void_p()
+        _chk(lib().dmx_engine_create(files, len(model_files), devs, len(devices) if devices else 0, max_batch, transport,
+                                     ctypes.byref(self.h)))
+        self.S = lib().dmx_engine_n_sources(self.h)
+        self.n_models = lib().dmx_engine_n_models(self.h)
+        self.n_devices = lib().dmx_engine_n_devices(self.h)
+        self.transport = lib().dmx_engine_transport(self.h)
+
+    def close(self):
+        if self.h:
+            lib().dmx_engine_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def track(self, audio: np.ndarray, shift_offsets, progress=None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """audio (2, n) planar -> (S, 2, n); one shift offset per model. `out`: reuse a result buffer."""
+        audio = np.ascontiguousarray(audio, np.float32)
+        n = audio.shape[1]
+        if out is None:
+            out = np.zeros((self.S, 2, n), np.float32)
+        assert out.shape == (self.S, 2, n) and out.dtype == np.float32 and out.flags.c_contiguous
+        so = (ctypes.c_int * self.n_models)(*shift_offsets)
+        cb = PROGRESS_FN(lambda p, m, u: progress(p, m.decode())) if progress else None
+        cbp = ctypes.cast(cb, ctypes.c_void_p) if cb else None
+        _chk(lib().dmx_engine_track_infer(self.h, audio.ctypes.data, n, so, out.ctypes.data, LAYOUT_PLANAR, cbp, None))
+        return out
 
 
 def igemm_timing(ctx: "Context", batch: int, op_name: str):

@@ -5,22 +5,17 @@
 //   model_inference    -> dmx_segment_infer*    (src/model_inference.cpp:48)
 //   demucs_inference   -> dmx_track_infer       (src/model_apply.cpp:60-288)
 // No CPU fallback exists: without a usable HIP device every compute entry point fails.
-#include "../../include/demucs_hip.h"
-#include "kernels.h"
+#include "api_internal.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
 
 using namespace dmx;
 
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...)
+int dmx_fail(int code, const char *fmt, ...)
 {
     char buf[1024];
     va_list ap;
@@ -30,47 +25,9 @@ static int fail(int code, const char *fmt, ...)
     g_err = buf;
     return code;
 }
-#define HIPCHK(expr)                                                                                          \
-    do                                                                                                        \
-    {                                                                                                         \
-        hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess)                                                                                 \
-            return fail(DMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-struct dmx_model
-{
-    PackedModel pm;
-    float *dW = nullptr;
-    int device = 0;
-};
-
-struct dmx_ctx
-{
-    const dmx_model *m = nullptr;
-    i64 seg = 0;
-    int maxBatch = 1;
-    std::map<int, std::unique_ptr<Plan>> plans;
-    float *dA = nullptr;
-    i64 arenaFloats = 0;
-    hipStream_t stream = nullptr;  // main / freq branch; every API call is ordered on this stream
-    hipStream_t ownStream = nullptr; // the stream created with the context (`stream` may be a caller's)
-    hipStream_t stream2 = nullptr; // time branch (forked from and joined back into `stream` inside run_plan)
-    int streamMode = 0;            // 0 auto (two streams for batches < kTwoStreamMaxBatch), 1 one stream, 2 always two (env DMX_STREAMS)
-    static const int kTwoStreamMaxBatch = 8;
-    std::vector<hipEvent_t> events; // one per op index (created on first use), + fork / join
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    int lastBatch = 0;
-    // caller buffers the plan reads its input from / writes its output to directly (device entry point):
-    // the arena regions [mixOff, +mixLen) and [outOff, +outLen) are redirected while they are set
-    const float *extMix = nullptr;
-    float *extOut = nullptr;
-    i64 redirMixOff = 0, redirMixLen = 0, redirOutOff = 0, redirOutLen = 0;
-    // track-level scratch
-    double *dPartials = nullptr;
-    int *dSegIdx = nullptr;
-    static const int kStatBlocks = 256;
-};
+const std::string &dmx_err_string() { return g_err; }
+void dmx_set_err_string(const std::string &s) { g_err = s; }
+#define fail dmx_fail
 
 extern "C" const char *dmx_last_error(void) { return g_err.c_str(); }
 
@@ -104,7 +61,12 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
     HIPCHK(hipSetDevice(device));
     // + 256 B: the igemm staging prefetches one K-tile beyond the last one (never used, must be readable)
     HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 256));
-    HIPCHK(hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    hipError_t e = hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        (void)hipFree(m->dW);
+        return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
+    }
     *out = m.release();
     return DMX_OK;
 }
@@ -158,21 +120,13 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     return raw;
 }
 
-extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out)
+static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int max_batch)
 {
-    if (!m || !out || max_batch < 1 || max_batch > 64)
-        return fail(DMX_ERR_ARG, "dmx_ctx_create: invalid argument");
-    *out = nullptr;
-    if (segment_samples == 0)
-        segment_samples = DMX_SEGMENT_SAMPLES;
-    if (segment_samples < 4096 || segment_samples % 2 != 0)
-        return fail(DMX_ERR_ARG, "dmx_ctx_create: segment_samples must be even and >= 4096");
-    auto c = std::make_unique<dmx_ctx>();
     c->m = m;
     c->seg = segment_samples;
     c->maxBatch = max_batch;
     HIPCHK(hipSetDevice(m->device));
-    Plan *p = get_plan(c.get(), max_batch);
+    Plan *p = get_plan(c, max_batch);
     std::string why;
     if (!validate_plan(*p, why))
         return fail(DMX_ERR_ARG, "dmx_ctx_create: unsupported geometry (%s)", why.c_str());
@@ -183,50 +137,104 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     HIPCHK(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     {
         const char *e = getenv("DMX_STREAMS");
         c->streamMode = e ? atoi(e) : 0;
+        const char *g = getenv("DMX_GRAPH");
+        c->graphMode = g ? atoi(g) : 1;
     }
     HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
-    HIPCHK(hipMalloc((void **)&c->dSegIdx, sizeof(int) * 4096));
+    HIPCHK(hipMalloc((void **)&c->dStats, sizeof(float) * 4));
+    return DMX_OK;
+}
+
+extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out)
+{
+    if (!m || !out || max_batch < 1 || max_batch > 64)
+        return fail(DMX_ERR_ARG, "dmx_ctx_create: invalid argument");
+    *out = nullptr;
+    if (segment_samples == 0)
+        segment_samples = DMX_SEGMENT_SAMPLES;
+    if (segment_samples < 4096 || segment_samples % 2 != 0)
+        return fail(DMX_ERR_ARG, "dmx_ctx_create: segment_samples must be even and >= 4096");
+    auto c = std::make_unique<dmx_ctx>(); // ~dmx_ctx releases whatever an early return leaves behind
+    DMXCHK(ctx_init(c.get(), m, segment_samples, max_batch));
     *out = c.release();
     return DMX_OK;
 }
 
-extern "C" void dmx_ctx_free(dmx_ctx *c)
+dmx_ctx::~dmx_ctx()
 {
-    if (!c)
+    if (!m)
         return;
-    (void)hipSetDevice(c->m->device);
-    if (c->stream)
-        (void)hipStreamSynchronize(c->stream);
-    if (c->ownStream)
-    {
-        (void)hipStreamSynchronize(c->ownStream);
-        (void)hipStreamDestroy(c->ownStream);
-    }
-    if (c->stream2)
-    {
-        (void)hipStreamSynchronize(c->stream2);
-        (void)hipStreamDestroy(c->stream2);
-    }
-    for (hipEvent_t e : c->events)
+    (void)hipSetDevice(m->device);
+    if (stream)
+        (void)hipStreamSynchronize(stream);
+    for (auto &kv : graphs)
+        (void)hipGraphExecDestroy(kv.second);
+    for (hipStream_t s : {ownStream, stream2, copyStream})
+        if (s)
+        {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (hipEvent_t e : events)
         if (e)
             (void)hipEventDestroy(e);
-    if (c->evFork)
-        (void)hipEventDestroy(c->evFork);
-    if (c->evJoin)
-        (void)hipEventDestroy(c->evJoin);
-    if (c->dA)
-        (void)hipFree(c->dA);
-    if (c->dPartials)
-        (void)hipFree(c->dPartials);
-    if (c->dSegIdx)
-        (void)hipFree(c->dSegIdx);
-    delete c;
+    for (hipEvent_t e : batchEvents)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (evFork)
+        (void)hipEventDestroy(evFork);
+    if (evJoin)
+        (void)hipEventDestroy(evJoin);
+    for (void *p : {(void *)dA, (void *)dPartials, (void *)dStats, (void *)bAudio.p, (void *)bTmp.p, (void *)bMix.p,
+                    (void *)bSegOut.p, (void *)bOut.p})
+        if (p)
+            (void)hipFree(p);
 }
+
+extern "C" void dmx_ctx_free(dmx_ctx *c) { delete c; }
+
+// Rebinds the context to another model of the SAME architecture on the same device (identical packed
+// layout => identical plan): the fine-tuned bag runs its four models through one arena.
+extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
+{
+    if (!c || !m)
+        return fail(DMX_ERR_ARG, "dmx_ctx_set_model: null argument");
+    if (m == c->m)
+        return DMX_OK;
+    if (m->device != c->m->device || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
+        m->pm.blob.size() != c->m->pm.blob.size() || m->pm.index != c->m->pm.index)
+        return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
+    c->m = m; // kernels of earlier calls hold the old weight pointer by value: no synchronisation needed
+    return DMX_OK;
+}
+
+int dmx_ensure_buf(DevBuf &b, i64 floats)
+{
+    if (b.cap >= floats)
+        return DMX_OK;
+    if (b.p)
+        HIPCHK(hipFree(b.p)); // hipFree synchronises the device: nothing still reads the old buffer
+    b.p = nullptr, b.cap = 0;
+    HIPCHK(hipMalloc((void **)&b.p, sizeof(float) * (size_t)floats));
+    b.cap = floats;
+    return DMX_OK;
+}
+
+hipEvent_t dmx_batch_event(dmx_ctx *c, size_t i)
+{
+    if (c->batchEvents.size() <= i)
+        c->batchEvents.resize(i + 1, nullptr);
+    if (!c->batchEvents[i] && hipEventCreateWithFlags(&c->batchEvents[i], hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    return c->batchEvents[i];
+}
+
 extern "C" int64_t dmx_ctx_segment_samples(const dmx_ctx *c) { return c ? c->seg : 0; }
 extern "C" int dmx_ctx_max_batch(const dmx_ctx *c) { return c ? c->maxBatch : 0; }
 extern "C" int64_t dmx_ctx_arena_bytes(const dmx_ctx *c) { return c ? c->arenaFloats * 4 : 0; }
@@ -252,7 +260,7 @@ extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
 
 // --------------------------------------------------------------------------- executor
 static unsigned long long *g_dbg = nullptr; // set only by dmx_debug_igemm_timing
-static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
+static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
 {
     float *A = c->dA;
     const float *W = c->m->dW;
@@ -286,7 +294,8 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
         if ((g.cfg == kDirectCfg ? launch_dgemm(k, s) : launch_igemm(g.cfg, k, s)) != 0)
-            fprintf(stderr, "[dmx] internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)\n", op.name.c_str(), g.cfg, g.pro, g.epi);
+            return fail(DMX_ERR_ARG, "internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)", op.name.c_str(), g.cfg, g.pro,
+                        g.epi);
         break;
     }
     case OP_STATS_REDUCE:
@@ -338,6 +347,45 @@ static void launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff
     default:
         break;
     }
+    return DMX_OK;
+}
+
+// enqueues the ops of the plan (one stream, or freq / time branch on two streams with the derived joins)
+static int enqueue_plan(dmx_ctx *c, Plan *p, bool two)
+{
+    if (!two)
+    {
+        for (const Op &op : p->ops)
+            DMXCHK(launch_op(c, op, c->stream, p->zeroOff));
+        return DMX_OK;
+    }
+    // freq branch on `stream`, time branch on `stream2`, joined by the waits plan.cpp derived from
+    // the ops' arena ranges (Op::waitOp / Op::signals); fork and join bracket the whole plan so
+    // that callers only ever need to order themselves against `stream`.
+    const size_t n = p->ops.size();
+    if (c->events.size() < n)
+        c->events.resize(n, nullptr);
+    HIPCHK(hipEventRecord(c->evFork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+    for (size_t i = 0; i < n; ++i)
+    {
+        const Op &op = p->ops[i];
+        if (op.kind == OP_TAP)
+            continue;
+        hipStream_t s = op.stream ? c->stream2 : c->stream;
+        if (op.waitOp >= 0)
+            HIPCHK(hipStreamWaitEvent(s, c->events[(size_t)op.waitOp], 0));
+        DMXCHK(launch_op(c, op, s, p->zeroOff));
+        if (op.signals)
+        {
+            if (!c->events[i])
+                HIPCHK(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(c->events[i], s));
+        }
+    }
+    HIPCHK(hipEventRecord(c->evJoin, c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+    return DMX_OK;
 }
 
 static int run_plan(dmx_ctx *c, int batch)
@@ -349,40 +397,61 @@ static int run_plan(dmx_ctx *c, int batch)
     // kernel's own duration stretches by the overlap); small batches gain up to 24 % from running the
     // freq and time branches concurrently.
     const bool two = c->streamMode == 2 || (c->streamMode == 0 && batch < dmx_ctx::kTwoStreamMaxBatch);
-    if (!two)
+    // Small batches are launch-bound (~330 kernels of ~20 us on two streams with 23 event joins): when the
+    // same call (same I/O buffers, model and batch) comes a second time in a row, the whole two-stream
+    // schedule is captured into a HIP graph and replayed from then on (shapes are static).
+    const bool graphable = c->graphMode == 1 && two && c->stream == c->ownStream;
+    const dmx_ctx::GraphKey key{c->extMix, c->extOut, c->m};
+    hipGraphExec_t exec = nullptr;
+    if (graphable)
     {
-        for (const Op &op : p->ops)
-            launch_op(c, op, c->stream, p->zeroOff);
-    }
-    else
-    {
-        // freq branch on `stream`, time branch on `stream2`, joined by the waits plan.cpp derived from
-        // the ops' arena ranges (Op::waitOp / Op::signals); fork and join bracket the whole plan so
-        // that callers only ever need to order themselves against `stream`.
-        const size_t n = p->ops.size();
-        if (c->events.size() < n)
-            c->events.resize(n, nullptr);
-        HIPCHK(hipEventRecord(c->evFork, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
-        for (size_t i = 0; i < n; ++i)
+        if (batch != c->graphBatch)
         {
-            const Op &op = p->ops[i];
-            if (op.kind == OP_TAP)
-                continue;
-            hipStream_t s = op.stream ? c->stream2 : c->stream;
-            if (op.waitOp >= 0)
-                HIPCHK(hipStreamWaitEvent(s, c->events[(size_t)op.waitOp], 0));
-            launch_op(c, op, s, p->zeroOff);
-            if (op.signals)
-            {
-                if (!c->events[i])
-                    HIPCHK(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
-                HIPCHK(hipEventRecord(c->events[i], s));
-            }
+            for (auto &kv : c->graphs)
+                (void)hipGraphExecDestroy(kv.second);
+            c->graphs.clear();
+            c->graphBatch = batch;
+            c->haveLastKey = false;
         }
-        HIPCHK(hipEventRecord(c->evJoin, c->stream2));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+        auto it = c->graphs.find(key);
+        if (it != c->graphs.end())
+            exec = it->second;
+        else if (c->haveLastKey && !(key < c->lastKey) && !(c->lastKey < key))
+        {
+            if (c->graphs.size() >= 8)
+            {
+                for (auto &kv : c->graphs)
+                    (void)hipGraphExecDestroy(kv.second);
+                c->graphs.clear();
+            }
+            // events recorded during the capture must exist beforehand
+            if (c->events.size() < p->ops.size())
+                c->events.resize(p->ops.size(), nullptr);
+            for (size_t i = 0; i < p->ops.size(); ++i)
+                if (p->ops[i].signals && !c->events[i])
+                    HIPCHK(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_plan(c, p, true);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (rc != DMX_OK || e != hipSuccess)
+            {
+                if (g)
+                    (void)hipGraphDestroy(g);
+                return rc != DMX_OK ? rc : fail(DMX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            }
+            const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess)
+                return fail(DMX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+            c->graphs.emplace(key, exec);
+        }
+        c->lastKey = key, c->haveLastKey = true;
     }
+    if (exec)
+        HIPCHK(hipGraphLaunch(exec, c->stream));
+    else
+        DMXCHK(enqueue_plan(c, p, two));
     c->lastBatch = batch;
     HIPCHK(hipGetLastError());
     return DMX_OK;
@@ -482,15 +551,31 @@ extern "C" int dmx_track_gather_device(dmx_ctx *c, const float *d_audio, int64_t
     HIPCHK(hipSetDevice(c->m->device));
     i64 len, stride;
     int nseg;
-    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
-    if (rc)
-        return rc;
+    DMXCHK(dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride));
     for (int i = 0; i < n_idx; ++i)
         if (seg_idx[i] < 0 || seg_idx[i] >= nseg)
             return fail(DMX_ERR_ARG, "dmx_track_gather_device: segment index %d out of range", seg_idx[i]);
-    HIPCHK(hipStreamSynchronize(c->stream)); // dSegIdx may still be in use by a previous gather
-    HIPCHK(hipMemcpyAsync(c->dSegIdx, seg_idx, sizeof(int) * (size_t)n_idx, hipMemcpyHostToDevice, c->stream));
-    launch_track_gather(d_audio, n, d_stats, shift_offset, c->seg, stride, len, c->dSegIdx, n_idx, d_mix, c->stream);
+    // the indices are kernel arguments (copied at launch): seg_idx may be reused as soon as this returns
+    launch_track_gather(d_audio, n, d_stats, shift_offset, c->seg, stride, len, seg_idx, n_idx, d_mix, c->stream);
+    HIPCHK(hipGetLastError());
+    return DMX_OK;
+}
+
+int dmx_track_overlap_add_planes(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
+                                 const float *d_stats, float *d_out, int layout, int planeBase, int nPlanes)
+{
+    if (!c || !d_seg_out || !d_stats || !d_out)
+        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: null argument");
+    if (layout != DMX_LAYOUT_EIGEN && layout != DMX_LAYOUT_PLANAR)
+        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: unknown layout %d", layout);
+    HIPCHK(hipSetDevice(c->m->device));
+    i64 len, stride;
+    int nseg;
+    DMXCHK(dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride));
+    if (n_segments != nseg)
+        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: expected %d segments, got %d", nseg, n_segments);
+    launch_track_ola(d_seg_out, nseg, c->m->pm.n_sources, c->seg, stride, len, n, shift_offset, d_stats, d_out,
+                     layout == DMX_LAYOUT_EIGEN ? 1 : 0, planeBase, nPlanes, 0, n, c->stream);
     HIPCHK(hipGetLastError());
     return DMX_OK;
 }
@@ -498,22 +583,20 @@ extern "C" int dmx_track_gather_device(dmx_ctx *c, const float *d_audio, int64_t
 extern "C" int dmx_track_overlap_add_device(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
                                             const float *d_stats, float *d_out, int layout)
 {
-    if (!c || !d_seg_out || !d_stats || !d_out)
+    if (!c)
         return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: null argument");
-    HIPCHK(hipSetDevice(c->m->device));
-    i64 len, stride;
-    int nseg;
-    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
-    if (rc)
-        return rc;
-    if (n_segments != nseg)
-        return fail(DMX_ERR_ARG, "dmx_track_overlap_add_device: expected %d segments, got %d", nseg, n_segments);
-    launch_track_ola(d_seg_out, nseg, c->m->pm.n_sources, c->seg, stride, len, n, shift_offset, d_stats, d_out,
-                     layout == DMX_LAYOUT_EIGEN ? 1 : 0, c->stream);
-    HIPCHK(hipGetLastError());
-    return DMX_OK;
+    return dmx_track_overlap_add_planes(c, d_seg_out, n_segments, n, shift_offset, d_stats, d_out, layout, 0,
+                                        2 * c->m->pm.n_sources);
 }
 
+// demucs_inference on one device. All device buffers belong to the context (grown on first use, then
+// reused: no allocation on the per-track path); every batch is enqueued without waiting for the one
+// before; progress is reported from per-batch events, i.e. the stream is never synchronised before the
+// end; and the track is FINISHED IN PIECES: as soon as the batch ending with segment g is enqueued, the
+// output samples below g*stride + (first sample of segment g+1) can no longer change, so their
+// overlap-add is launched right behind that batch and their device-to-host copy runs on a second stream
+// underneath the kernels of the following batch (the 339 MB result of a 4-minute track otherwise costs
+// as much wall time after the last kernel as a dozen segments).
 extern "C" int dmx_track_infer(dmx_ctx *c, const float *audio, int64_t n, int shift_offset, float *out, int layout,
                                dmx_progress_fn progress, void *user)
 {
@@ -530,77 +613,81 @@ extern "C" int dmx_track_infer(dmx_ctx *c, const float *audio, int64_t n, int sh
     const i64 seg = c->seg;
     i64 len, stride;
     int nseg;
-    int rc = dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride);
-    if (rc)
-        return rc;
-    float *dAudio = nullptr, *dTmp = nullptr, *dStats = nullptr, *dMix = nullptr, *dSegOut = nullptr, *dOut = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(dAudio);
-        (void)hipFree(dTmp);
-        (void)hipFree(dStats);
-        (void)hipFree(dMix);
-        (void)hipFree(dSegOut);
-        (void)hipFree(dOut);
-    };
-#define TRY(expr)                   \
-    do                              \
-    {                               \
-        int rc_ = (expr);           \
-        if (rc_)                    \
-        {                           \
-            cleanup();              \
-            return rc_;             \
-        }                           \
-    } while (0)
-#define TRYHIP(expr)                                                                            \
-    do                                                                                          \
-    {                                                                                           \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-        {                                                                                       \
-            cleanup();                                                                          \
-            return fail(DMX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
-        }                                                                                       \
-    } while (0)
-    TRYHIP(hipMalloc((void **)&dAudio, sizeof(float) * 2 * (size_t)n));
-    TRYHIP(hipMalloc((void **)&dStats, sizeof(float) * 4));
-    TRYHIP(hipMalloc((void **)&dMix, sizeof(float) * 2 * (size_t)seg * c->maxBatch));
-    TRYHIP(hipMalloc((void **)&dSegOut, sizeof(float) * (size_t)nseg * S * 2 * seg));
-    TRYHIP(hipMalloc((void **)&dOut, sizeof(float) * (size_t)S * 2 * n));
+    DMXCHK(dmx_track_geometry(c, n, shift_offset, &len, &nseg, &stride));
+    DMXCHK(dmx_ensure_buf(c->bAudio, 2 * n));
+    DMXCHK(dmx_ensure_buf(c->bMix, 2 * seg * c->maxBatch));
+    DMXCHK(dmx_ensure_buf(c->bSegOut, (i64)nseg * S * 2 * seg));
+    DMXCHK(dmx_ensure_buf(c->bOut, (i64)S * 2 * n));
+    float *dAudio = c->bAudio.p, *dMix = c->bMix.p, *dSegOut = c->bSegOut.p, *dOut = c->bOut.p;
     if (layout == DMX_LAYOUT_EIGEN)
-        TRYHIP(hipMemcpyAsync(dAudio, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dAudio, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     else
     {
-        TRYHIP(hipMalloc((void **)&dTmp, sizeof(float) * 2 * (size_t)n));
-        TRYHIP(hipMemcpyAsync(dTmp, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        launch_planar_to_interleaved(dTmp, dAudio, n, c->stream);
+        DMXCHK(dmx_ensure_buf(c->bTmp, 2 * n));
+        HIPCHK(hipMemcpyAsync(c->bTmp.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        launch_planar_to_interleaved(c->bTmp.p, dAudio, n, c->stream);
     }
     if (progress)
         progress(0.0f, "1., apply model w/ shift", user);
-    TRY(dmx_track_stats_device(c, dAudio, n, dStats));
+    DMXCHK(dmx_track_stats_device(c, dAudio, n, c->dStats));
+    const int nBatches = (nseg + c->maxBatch - 1) / c->maxBatch;
     std::vector<int> idx;
-    for (int g0 = 0; g0 < nseg; g0 += c->maxBatch)
-    {
-        int nb = std::min(c->maxBatch, nseg - g0);
-        idx.resize((size_t)nb);
-        for (int i = 0; i < nb; ++i)
-            idx[(size_t)i] = g0 + i;
-        TRY(dmx_track_gather_device(c, dAudio, n, dStats, shift_offset, idx.data(), nb, dMix));
-        TRY(dmx_segment_infer_device(c, dMix, dSegOut + (size_t)g0 * S * 2 * seg, nb));
+    // the piecewise finish needs the planar layout (a piece is a contiguous run per plane); the Eigen image
+    // interleaves stems and channels per sample, so a piece is contiguous there too: [i0*2S, i1*2S)
+    // Piece k = output samples [lo[k], hi[k]) that are final once batch k is done. Its copy is issued
+    // AFTER batch k+1 has been enqueued: a device-to-host copy into pageable memory blocks the calling
+    // thread until the data has left the GPU, and the GPU must have its next batch queued by then.
+    std::vector<i64> lo((size_t)nBatches), hi((size_t)nBatches);
+    auto copy_piece = [&](int k) -> int {
+        const i64 i0 = lo[(size_t)k], i1 = hi[(size_t)k];
+        if (i1 > i0)
+        {
+            HIPCHK(hipStreamWaitEvent(c->copyStream, c->batchEvents[(size_t)k], 0));
+            if (layout == DMX_LAYOUT_EIGEN)
+                HIPCHK(hipMemcpyAsync(out + (size_t)i0 * 2 * S, dOut + (size_t)i0 * 2 * S, sizeof(float) * (size_t)(i1 - i0) * 2 * S,
+                                      hipMemcpyDeviceToHost, c->copyStream));
+            else
+                for (int pl = 0; pl < 2 * S; ++pl)
+                    HIPCHK(hipMemcpyAsync(out + (size_t)pl * n + i0, dOut + (size_t)pl * n + i0, sizeof(float) * (size_t)(i1 - i0),
+                                          hipMemcpyDeviceToHost, c->copyStream));
+        }
         if (progress)
         {
-            TRYHIP(hipStreamSynchronize(c->stream));
+            const int g0 = k * c->maxBatch, nb = std::min(c->maxBatch, nseg - g0);
+            HIPCHK(hipEventSynchronize(c->batchEvents[(size_t)k]));
             char msg[128];
             snprintf(msg, sizeof(msg), "2., apply model w/ split, segments %d..%d of %d", g0, g0 + nb - 1, nseg);
             progress((float)(g0 + nb) / (float)nseg, msg, user);
         }
+        return DMX_OK;
+    };
+    i64 done = 0; // output samples [0, done) are final
+    for (int k = 0; k < nBatches; ++k)
+    {
+        const int g0 = k * c->maxBatch, nb = std::min(c->maxBatch, nseg - g0);
+        idx.resize((size_t)nb);
+        for (int i = 0; i < nb; ++i)
+            idx[(size_t)i] = g0 + i;
+        DMXCHK(dmx_track_gather_device(c, dAudio, n, c->dStats, shift_offset, idx.data(), nb, dMix));
+        DMXCHK(dmx_segment_infer_device(c, dMix, dSegOut + (size_t)g0 * S * 2 * seg, nb));
+        // shifted-track positions below (g0+nb)*stride are covered only by segments < g0+nb
+        i64 fin = k == nBatches - 1 ? n : (i64)(g0 + nb) * stride - (DMX_MAX_SHIFT - shift_offset);
+        fin = std::max<i64>(done, std::min<i64>(fin, n));
+        lo[(size_t)k] = done, hi[(size_t)k] = fin;
+        launch_track_ola(dSegOut, nseg, S, seg, stride, len, n, shift_offset, c->dStats, dOut, layout == DMX_LAYOUT_EIGEN ? 1 : 0, 0,
+                         2 * S, done, fin, c->stream);
+        HIPCHK(hipGetLastError());
+        done = fin;
+        hipEvent_t ev = dmx_batch_event(c, (size_t)k);
+        if (!ev)
+            return fail(DMX_ERR_HIP, "dmx_track_infer: hipEventCreate failed");
+        HIPCHK(hipEventRecord(ev, c->stream));
+        if (k > 0)
+            DMXCHK(copy_piece(k - 1));
     }
-    TRY(dmx_track_overlap_add_device(c, dSegOut, nseg, n, shift_offset, dStats, dOut, layout));
-    TRYHIP(hipMemcpyAsync(out, dOut, sizeof(float) * (size_t)S * 2 * n, hipMemcpyDeviceToHost, c->stream));
-    TRYHIP(hipStreamSynchronize(c->stream));
-    cleanup();
-#undef TRY
-#undef TRYHIP
+    DMXCHK(copy_piece(nBatches - 1));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->copyStream));
     return DMX_OK;
 }
 

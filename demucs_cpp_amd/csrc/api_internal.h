@@ -1,0 +1,102 @@
+// api_internal.h — host-side state shared by api.cpp (single-context C ABI) and engine.cpp
+// (multi-device / multi-model scheduler). Nothing here crosses the C ABI.
+#pragma once
+#include "../../include/demucs_hip.h"
+#include "kernels.h"
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+int dmx_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+const std::string &dmx_err_string();         // last error of the calling thread
+void dmx_set_err_string(const std::string &); // adopt an error produced on another thread
+
+#define HIPCHK(expr)                                                                                              \
+    do                                                                                                            \
+    {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return dmx_fail(DMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define DMXCHK(expr)        \
+    do                      \
+    {                       \
+        int rc_ = (expr);   \
+        if (rc_ != DMX_OK)  \
+            return rc_;     \
+    } while (0)
+
+struct dmx_model
+{
+    dmx::PackedModel pm;
+    float *dW = nullptr;
+    int device = 0;
+};
+
+// grow-only device buffer owned by a context (track-level scratch: allocated on first use, reused by
+// every later call, freed with the context — no hipMalloc/hipFree on the per-track path)
+struct DevBuf
+{
+    float *p = nullptr;
+    dmx::i64 cap = 0; // floats
+};
+
+struct dmx_ctx
+{
+    const dmx_model *m = nullptr;
+    dmx::i64 seg = 0;
+    int maxBatch = 1;
+    std::map<int, std::unique_ptr<dmx::Plan>> plans;
+    float *dA = nullptr;
+    dmx::i64 arenaFloats = 0;
+    hipStream_t stream = nullptr;    // main / freq branch; every API call is ordered on this stream
+    hipStream_t ownStream = nullptr; // the stream created with the context (`stream` may be a caller's)
+    hipStream_t stream2 = nullptr;   // time branch (forked from and joined back into `stream` inside run_plan)
+    hipStream_t copyStream = nullptr; // D2H of finished parts of a track behind the kernels of later segments
+    int streamMode = 0;              // 0 auto (two streams for batches < kTwoStreamMaxBatch), 1 one stream, 2 always two (env DMX_STREAMS)
+    static const int kTwoStreamMaxBatch = 8;
+    std::vector<hipEvent_t> events; // one per op index (created on first use), + fork / join
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    int lastBatch = 0;
+    // caller buffers the plan reads its input from / writes its output to directly (device entry point):
+    // the arena regions [mixOff, +mixLen) and [outOff, +outLen) are redirected while they are set
+    const float *extMix = nullptr;
+    float *extOut = nullptr;
+    dmx::i64 redirMixOff = 0, redirMixLen = 0, redirOutOff = 0, redirOutLen = 0;
+    // track-level scratch
+    double *dPartials = nullptr;
+    static const int kStatBlocks = 256;
+    DevBuf bAudio, bTmp, bMix, bSegOut, bOut;
+    float *dStats = nullptr;            // 4 floats
+    std::vector<hipEvent_t> batchEvents; // progress reporting without host synchronisation of the stream
+    // HIP graphs of the batch-1 plan (launch-bound latency path), keyed by the redirected I/O pointers
+    struct GraphKey
+    {
+        const float *mix;
+        float *out;
+        const dmx_model *m;
+        bool operator<(const GraphKey &o) const
+        {
+            if (mix != o.mix)
+                return mix < o.mix;
+            if (out != o.out)
+                return out < o.out;
+            return m < o.m;
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int graphMode = 1; // env DMX_GRAPH: 0 off, 1 (default) capture the two-stream plans of small batches into HIP graphs
+    int graphBatch = 0; // batch size the cached graphs were captured for
+    GraphKey lastKey{nullptr, nullptr, nullptr};
+    bool haveLastKey = false;
+    ~dmx_ctx();
+};
+
+// ---- internal entry points used by engine.cpp
+int dmx_ensure_buf(DevBuf &b, dmx::i64 floats);
+// OLA of a plane range: planes [planeBase, planeBase + nPlanes) of the (S, 2, n) result
+int dmx_track_overlap_add_planes(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
+                                 const float *d_stats, float *d_out, int layout, int planeBase, int nPlanes);
+hipEvent_t dmx_batch_event(dmx_ctx *c, size_t i);

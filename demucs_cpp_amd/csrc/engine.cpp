@@ -1,0 +1,520 @@
+// engine.cpp — demucs_inference over several GPUs of one node and over a bag of models, in one process.
+//
+// Replaces, for a caller with more than one MI355X (or more than one model), the loop nest of
+//   cli-apps/demucs_ft.cpp:221-241   (four demucs_inference calls, stem i from model i)
+//   src/model_apply.cpp:189-235      (for each overlapping segment: segment_inference)
+// (/root/reference). That nest is embarrassingly parallel: every (model m, segment i) work item reads a
+// slice of the shifted track and produces an independent (S, 2, segment) block; the only coupling is
+// the weighted overlap-add of one model's blocks. So:
+//
+//   * work items are enumerated model-major, (m, 0..n_seg(m)-1) with n_seg(m) from model m's own shift
+//     offset (model_apply.cpp:114), T items in total;
+//   * logical device l owns the CONTIGUOUS item range [l*T/G, (l+1)*T/G): at most two models per device
+//     for the bag of 4 on 8 GPUs (21 items = one batch each), one contiguous slab of results per
+//     (device, model) run, and every item costs the same (short tails are zero-padded, Q8);
+//   * each device runs on its own host thread, stream and context (weights replicated: 170 MB fp32 per
+//     model), batches of <= max_batch items through dmx_segment_infer_device;
+//   * ONE exchange step: every (device, model) slab is gathered into the root device's
+//     [n_seg][S][2][segment] buffer of that model -
+//         transport RCCL : ncclSend on the owner / grouped ncclRecv on the root, one communicator per
+//                          device from ncclCommInitAll (xGMI; 11 MB per 4-source segment);
+//         transport P2P  : hipMemcpyPeerAsync pushed by the owner (SDMA over xGMI, no CU on either side);
+//                          also the only transport when one HIP device backs several logical devices
+//                          (tests on a 1-GPU box), where RCCL cannot build a communicator;
+//   * the root overlap-adds every model's blocks in segment order (bit-identical to the 1-device result:
+//     each output sample accumulates its <= 2 covering segments in increasing index), takes stem m from
+//     model m for a bag, de-normalises and copies out.
+//
+// librccl is bound lazily with dlopen the first time an RCCL engine is created: single-device users and
+// torch.distributed processes (which bring their own copy) never load a second RCCL.
+#include "api_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <thread>
+
+using namespace dmx;
+
+// ---- the part of the RCCL API used here (rccl.h), bound at run time
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t; // ncclSuccess == 0
+static const int kNcclFloat = 7; // ncclFloat32 (rccl.h: ncclInt8 0, ..., ncclFloat16 6, ncclFloat32 7)
+struct RcclApi
+{
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+static RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+                break;
+        if (!api.handle)
+        {
+            api.why = std::string("cannot load librccl: ") + dlerror();
+            return;
+        }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(api.handle, n);
+            if (!p)
+                api.why += std::string(" missing symbol ") + n;
+            return p;
+        };
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+#define NCCLCHK(expr)                                                                                     \
+    do                                                                                                    \
+    {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != 0)                                                                                      \
+            return dmx_fail(DMX_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString(r_));           \
+    } while (0)
+
+struct EngineDev
+{
+    int dev = 0;                     // HIP device id (several logical devices may share one)
+    std::vector<dmx_model *> models; // replica of every model on this device
+    dmx_ctx *ctx = nullptr;          // one arena, rebound to the model of the run (dmx_ctx_set_model)
+    DevBuf slab;                     // results of this device's items (non-root devices)
+    ncclComm_t comm = nullptr;
+    hipEvent_t evDone = nullptr;
+    // result of the last call's worker
+    int rc = DMX_OK;
+    std::string err;
+};
+
+struct dmx_engine
+{
+    int nModels = 0, S = 0, maxBatch = 0, transport = DMX_TRANSPORT_P2P;
+    i64 seg = 0;
+    std::vector<EngineDev> devs;
+    std::vector<DevBuf> segOut; // root: per model [n_seg][S][2][seg]
+    DevBuf out;                 // root: (S, 2, n)
+    std::mutex mu;              // one track at a time per engine: demucs_inference is called concurrently on a
+                                // shared const model by the reference's threaded driver (threaded_inference.hpp:105-123)
+    ~dmx_engine()
+    {
+        RcclApi *api = transport == DMX_TRANSPORT_RCCL ? rccl_api() : nullptr;
+        for (EngineDev &d : devs)
+        {
+            (void)hipSetDevice(d.dev);
+            if (d.comm && api && api->CommDestroy)
+                (void)api->CommDestroy(d.comm);
+            if (d.evDone)
+                (void)hipEventDestroy(d.evDone);
+            delete d.ctx; // before the models it points to
+            if (d.slab.p)
+                (void)hipFree(d.slab.p);
+            for (dmx_model *m : d.models)
+                dmx_model_free(m);
+        }
+        if (!devs.empty())
+        {
+            (void)hipSetDevice(devs[0].dev);
+            for (DevBuf &b : segOut)
+                if (b.p)
+                    (void)hipFree(b.p);
+            if (out.p)
+                (void)hipFree(out.p);
+        }
+    }
+};
+
+extern "C" int dmx_engine_create(const char *const *model_files, int n_models, const int *devices, int n_devices, int max_batch,
+                                 int transport, dmx_engine **out)
+{
+    if (!model_files || !out || n_models < 1 || n_models > 16 || (n_devices > 0 && !devices) || n_devices > 64 || max_batch < 1 ||
+        max_batch > 64)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: invalid argument");
+    *out = nullptr;
+    const int visible = dmx_device_count();
+    if (visible <= 0)
+    {
+        // same order of failures as dmx_model_load: an unreadable / malformed file is reported as such,
+        // a good file fails with DMX_ERR_NO_DEVICE (there is no CPU fallback)
+        dmx_model *h = nullptr;
+        const int rc = dmx_model_load(model_files[0], 0, &h);
+        return rc != DMX_OK ? rc : dmx_fail(DMX_ERR_NO_DEVICE, "dmx_engine_create: no HIP device available");
+    }
+    auto e = std::make_unique<dmx_engine>();
+    e->nModels = n_models;
+    e->maxBatch = max_batch;
+    std::vector<int> devs;
+    if (n_devices <= 0) // all visible devices
+        for (int i = 0; i < visible; ++i)
+            devs.push_back(i);
+    else
+        devs.assign(devices, devices + n_devices);
+    bool distinct = true;
+    for (size_t i = 0; i < devs.size(); ++i)
+    {
+        if (devs[i] < 0 || devs[i] >= visible)
+            return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: device %d out of range (have %d)", devs[i], visible);
+        for (size_t j = 0; j < i; ++j)
+            distinct = distinct && devs[j] != devs[i];
+    }
+    if (transport == DMX_TRANSPORT_AUTO)
+    {
+        const char *env = getenv("DMX_GATHER");
+        if (env && !strcmp(env, "p2p"))
+            transport = DMX_TRANSPORT_P2P;
+        else if (env && !strcmp(env, "rccl"))
+            transport = DMX_TRANSPORT_RCCL;
+        else
+            transport = (distinct && devs.size() > 1) ? DMX_TRANSPORT_RCCL : DMX_TRANSPORT_P2P;
+    }
+    if (transport != DMX_TRANSPORT_P2P && transport != DMX_TRANSPORT_RCCL)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: unknown transport %d", transport);
+    if (transport == DMX_TRANSPORT_RCCL && !distinct)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the RCCL transport needs distinct devices (a communicator holds a GPU once)");
+    e->transport = transport;
+    e->devs.resize(devs.size());
+    for (size_t l = 0; l < devs.size(); ++l)
+    {
+        EngineDev &d = e->devs[l];
+        d.dev = devs[l];
+        for (int m = 0; m < n_models; ++m)
+        {
+            dmx_model *h = nullptr;
+            DMXCHK(dmx_model_load(model_files[m], d.dev, &h));
+            d.models.push_back(h);
+            if (dmx_model_n_sources(h) != dmx_model_n_sources(d.models[0]))
+                return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the models of a bag must have the same number of sources");
+        }
+        DMXCHK(dmx_ctx_create(d.models[0], 0, max_batch, &d.ctx));
+        for (int m = 1; m < n_models; ++m) // every model must fit the one plan
+        {
+            DMXCHK(dmx_ctx_set_model(d.ctx, d.models[(size_t)m]));
+        }
+        DMXCHK(dmx_ctx_set_model(d.ctx, d.models[0]));
+        HIPCHK(hipSetDevice(d.dev));
+        HIPCHK(hipEventCreateWithFlags(&d.evDone, hipEventDisableTiming));
+    }
+    e->S = dmx_model_n_sources(e->devs[0].models[0]);
+    e->seg = e->devs[0].ctx->seg;
+    if (n_models > 1 && n_models != e->S)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: a bag needs one model per source (%d models, %d sources): stem i is taken from model i",
+                        n_models, e->S);
+    e->segOut.resize((size_t)n_models);
+    if (devs.size() > 1 && distinct)
+        for (size_t l = 1; l < devs.size(); ++l) // direct xGMI copies between the root and every peer
+        {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[l], devs[0]) == hipSuccess && can)
+            {
+                (void)hipSetDevice(devs[l]);
+                hipError_t pe = hipDeviceEnablePeerAccess(devs[0], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return dmx_fail(DMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", devs[l], devs[0], hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+        }
+    if (transport == DMX_TRANSPORT_RCCL)
+    {
+        RcclApi *api = rccl_api();
+        if (!api->handle || !api->why.empty())
+            return dmx_fail(DMX_ERR_HIP, "dmx_engine_create: RCCL transport unavailable (%s); DMX_GATHER=p2p selects peer copies", api->why.c_str());
+        std::vector<ncclComm_t> comms(devs.size(), nullptr);
+        NCCLCHK(api->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        for (size_t l = 0; l < devs.size(); ++l)
+            e->devs[l].comm = comms[l];
+    }
+    *out = e.release();
+    return DMX_OK;
+}
+
+extern "C" void dmx_engine_free(dmx_engine *e) { delete e; }
+extern "C" int dmx_engine_n_devices(const dmx_engine *e) { return e ? (int)e->devs.size() : 0; }
+extern "C" int dmx_engine_n_models(const dmx_engine *e) { return e ? e->nModels : 0; }
+extern "C" int dmx_engine_n_sources(const dmx_engine *e) { return e ? e->S : 0; }
+extern "C" int dmx_engine_transport(const dmx_engine *e) { return e ? e->transport : -1; }
+extern "C" dmx_ctx *dmx_engine_root_ctx(dmx_engine *e, int model)
+{
+    if (!e || model < 0 || model >= e->nModels)
+        return nullptr;
+    if (dmx_ctx_set_model(e->devs[0].ctx, e->devs[0].models[(size_t)model]) != DMX_OK)
+        return nullptr;
+    return e->devs[0].ctx;
+}
+
+namespace
+{
+struct Run // a maximal stretch of one device's items that belongs to one model
+{
+    int model, g0, g1;  // segments [g0, g1) of `model`
+    i64 slabOff;        // float offset of the run's results in the device's slab
+};
+struct Shared
+{
+    std::mutex mu;
+    std::condition_variable cv;
+    int itemsDone = 0;
+    int workersLeft = 0;
+    std::vector<std::string> messages; // progress lines waiting for the calling thread
+};
+} // namespace
+
+// items of model m: first global item index
+static void partition(const std::vector<int> &nseg, int G, std::vector<std::vector<Run>> &runs)
+{
+    int T = 0;
+    for (int v : nseg)
+        T += v;
+    runs.assign((size_t)G, {});
+    for (int l = 0; l < G; ++l)
+    {
+        const int lo = (int)((i64)l * T / G), hi = (int)((i64)(l + 1) * T / G);
+        int base = 0;
+        i64 off = 0;
+        for (int m = 0; m < (int)nseg.size(); ++m)
+        {
+            const int a = std::max(lo, base), b = std::min(hi, base + nseg[(size_t)m]);
+            if (b > a)
+            {
+                runs[(size_t)l].push_back(Run{m, a - base, b - base, off});
+                off += b - a;
+            }
+            base += nseg[(size_t)m];
+        }
+    }
+}
+
+// pure host function, exported so that the dealing can be checked without a GPU (tests/test_engine_cpu.py):
+// runs[(l*n_models + m)*2 + {0,1}] = segment range [g0, g1) of model m owned by logical device l
+extern "C" int dmx_engine_partition(const int *n_segments, int n_models, int n_devices, int *runs_out)
+{
+    if (!n_segments || !runs_out || n_models < 1 || n_devices < 1)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_partition: invalid argument");
+    std::vector<int> nseg(n_segments, n_segments + n_models);
+    std::vector<std::vector<Run>> runs;
+    partition(nseg, n_devices, runs);
+    for (int i = 0; i < n_devices * n_models * 2; ++i)
+        runs_out[i] = 0;
+    for (int l = 0; l < n_devices; ++l)
+        for (const Run &r : runs[(size_t)l])
+        {
+            runs_out[(l * n_models + r.model) * 2] = r.g0;
+            runs_out[(l * n_models + r.model) * 2 + 1] = r.g1;
+        }
+    return DMX_OK;
+}
+
+// what logical device l does for one track (on its own host thread)
+static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64 n, const std::vector<int> &shifts,
+                       const std::vector<int> &nseg, const std::vector<Run> &runs, const std::vector<std::vector<Run>> &allRuns,
+                       Shared &sh)
+{
+    EngineDev &d = e->devs[(size_t)l];
+    dmx_ctx *c = d.ctx;
+    const int S = e->S;
+    const i64 seg = e->seg, blk = (i64)S * 2 * seg;
+    HIPCHK(hipSetDevice(d.dev));
+    if (!runs.empty() || l == 0)
+    {
+        // every device holds the (small) track and computes the same statistics locally
+        if (layout == DMX_LAYOUT_EIGEN)
+            HIPCHK(hipMemcpyAsync(c->bAudio.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        else
+        {
+            HIPCHK(hipMemcpyAsync(c->bTmp.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            launch_planar_to_interleaved(c->bTmp.p, c->bAudio.p, n, c->stream);
+        }
+        DMXCHK(dmx_track_stats_device(c, c->bAudio.p, n, c->dStats));
+    }
+    std::vector<int> idx;
+    size_t nev = 0;
+    std::vector<int> evItems;
+    for (const Run &r : runs)
+    {
+        DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
+        float *dst = l == 0 ? e->segOut[(size_t)r.model].p + (i64)r.g0 * blk : d.slab.p + r.slabOff * blk;
+        for (int g = r.g0; g < r.g1; g += e->maxBatch)
+        {
+            const int nb = std::min(e->maxBatch, r.g1 - g);
+            idx.resize((size_t)nb);
+            for (int i = 0; i < nb; ++i)
+                idx[(size_t)i] = g + i;
+            DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
+            DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
+            hipEvent_t ev = dmx_batch_event(c, nev++);
+            if (!ev)
+                return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
+            HIPCHK(hipEventRecord(ev, c->stream));
+            evItems.push_back(nb);
+        }
+    }
+    // ---- the exchange step
+    if (e->transport == DMX_TRANSPORT_RCCL && e->devs.size() > 1)
+    {
+        RcclApi *api = rccl_api();
+        if (l != 0)
+        {
+            for (const Run &r : runs) // one message per (device, model) run, in run order
+                NCCLCHK(api->Send(d.slab.p + r.slabOff * blk, (size_t)((i64)(r.g1 - r.g0) * blk), kNcclFloat, 0, d.comm, c->stream));
+        }
+        else
+        {
+            NCCLCHK(api->GroupStart());
+            for (size_t p = 1; p < allRuns.size(); ++p)
+                for (const Run &r : allRuns[p])
+                    NCCLCHK(api->Recv(e->segOut[(size_t)r.model].p + (i64)r.g0 * blk, (size_t)((i64)(r.g1 - r.g0) * blk), kNcclFloat, (int)p,
+                                      d.comm, c->stream));
+            NCCLCHK(api->GroupEnd());
+        }
+    }
+    else if (l != 0)
+    {
+        const int rootDev = e->devs[0].dev;
+        for (const Run &r : runs)
+            HIPCHK(hipMemcpyPeerAsync(e->segOut[(size_t)r.model].p + (i64)r.g0 * blk, rootDev, d.slab.p + r.slabOff * blk, d.dev,
+                                      sizeof(float) * (size_t)((i64)(r.g1 - r.g0) * blk), c->stream));
+    }
+    (void)nseg;
+    // ---- progress: one line per finished batch, delivered by the calling thread
+    for (size_t k = 0; k < nev; ++k)
+    {
+        HIPCHK(hipEventSynchronize(c->batchEvents[k]));
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.itemsDone += evItems[k];
+        char msg[160];
+        snprintf(msg, sizeof(msg), "2., apply model w/ split, device %d (gpu %d) finished %d segments", l, d.dev, evItems[k]);
+        sh.messages.push_back(msg);
+        sh.cv.notify_all();
+    }
+    HIPCHK(hipStreamSynchronize(c->stream)); // the slab has reached the root (or the root has received every slab)
+    return DMX_OK;
+}
+
+extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t n, const int *shift_offsets, float *out, int layout,
+                                      dmx_progress_fn progress, void *user)
+{
+    if (!e || !audio || !out || n < 2)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_track_infer: invalid argument");
+    if (layout != DMX_LAYOUT_EIGEN && layout != DMX_LAYOUT_PLANAR)
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_track_infer: unknown layout %d", layout);
+    std::lock_guard<std::mutex> guard(e->mu);
+    const int G = (int)e->devs.size(), M = e->nModels, S = e->S;
+    if (G == 1 && M == 1) // nothing to shard: the single-context path (same kernels, same bits; finishes the track in pieces)
+        return dmx_track_infer(e->devs[0].ctx, audio, n, shift_offsets ? shift_offsets[0] : -1, out, layout, progress, user);
+    const i64 seg = e->seg, blk = (i64)S * 2 * seg;
+    std::vector<int> shifts((size_t)M), nseg((size_t)M);
+    std::vector<i64> lens((size_t)M);
+    i64 stride = 0;
+    int T = 0;
+    for (int m = 0; m < M; ++m)
+    {
+        int so = shift_offsets ? shift_offsets[m] : -1;
+        if (so < 0)
+            so = rand() % DMX_MAX_SHIFT; // one draw per model, in model order (demucs_ft.cpp:221-231 -> model_apply.cpp:114)
+        if (so >= DMX_MAX_SHIFT)
+            return dmx_fail(DMX_ERR_ARG, "dmx_engine_track_infer: shift_offset must be < %d", DMX_MAX_SHIFT);
+        shifts[(size_t)m] = so;
+        DMXCHK(dmx_track_geometry(e->devs[0].ctx, n, so, &lens[(size_t)m], &nseg[(size_t)m], &stride));
+        T += nseg[(size_t)m];
+    }
+    std::vector<std::vector<Run>> runs;
+    partition(nseg, G, runs);
+    // ---- buffers (grown on first use, reused afterwards)
+    for (int l = 0; l < G; ++l)
+    {
+        EngineDev &d = e->devs[(size_t)l];
+        HIPCHK(hipSetDevice(d.dev));
+        if (runs[(size_t)l].empty() && l != 0)
+            continue;
+        DMXCHK(dmx_ensure_buf(d.ctx->bAudio, 2 * n));
+        if (layout == DMX_LAYOUT_PLANAR)
+            DMXCHK(dmx_ensure_buf(d.ctx->bTmp, 2 * n));
+        DMXCHK(dmx_ensure_buf(d.ctx->bMix, 2 * seg * e->maxBatch));
+        if (l != 0)
+        {
+            i64 items = 0;
+            for (const Run &r : runs[(size_t)l])
+                items += r.g1 - r.g0;
+            DMXCHK(dmx_ensure_buf(d.slab, items * blk));
+        }
+    }
+    HIPCHK(hipSetDevice(e->devs[0].dev));
+    for (int m = 0; m < M; ++m)
+        DMXCHK(dmx_ensure_buf(e->segOut[(size_t)m], (i64)nseg[(size_t)m] * blk));
+    DMXCHK(dmx_ensure_buf(e->out, (i64)S * 2 * n));
+    if (progress)
+        progress(0.0f, "1., apply model w/ shift", user);
+    // ---- one host thread per device; this thread delivers the progress lines (the reference invokes the
+    // callback synchronously on the caller's thread, src/model.hpp:17)
+    Shared sh;
+    sh.workersLeft = G;
+    std::vector<std::thread> threads;
+    for (int l = 0; l < G; ++l)
+        threads.emplace_back([&, l] {
+            EngineDev &d = e->devs[(size_t)l];
+            d.rc = device_work(e, l, audio, layout, n, shifts, nseg, runs[(size_t)l], runs, sh);
+            d.err = d.rc == DMX_OK ? std::string() : dmx_err_string();
+            std::lock_guard<std::mutex> lk(sh.mu);
+            --sh.workersLeft;
+            sh.cv.notify_all();
+        });
+    {
+        std::unique_lock<std::mutex> lk(sh.mu);
+        for (;;)
+        {
+            sh.cv.wait(lk, [&] { return !sh.messages.empty() || sh.workersLeft == 0; });
+            std::vector<std::string> msgs;
+            msgs.swap(sh.messages);
+            const float frac = T > 0 ? (float)sh.itemsDone / (float)T : 1.0f;
+            const bool finished = sh.workersLeft == 0;
+            lk.unlock();
+            if (progress)
+                for (const std::string &s : msgs)
+                    progress(frac, s.c_str(), user);
+            lk.lock();
+            if (finished && sh.messages.empty())
+                break;
+        }
+    }
+    for (std::thread &t : threads)
+        t.join();
+    for (int l = 0; l < G; ++l)
+        if (e->devs[(size_t)l].rc != DMX_OK)
+        {
+            dmx_set_err_string("device " + std::to_string(l) + ": " + e->devs[(size_t)l].err);
+            return e->devs[(size_t)l].rc;
+        }
+    // ---- root: overlap-add per model in segment order, stem m from model m for a bag
+    // (model_apply.cpp:171-246; demucs_ft.cpp:238-241), de-normalise, copy out
+    EngineDev &r0 = e->devs[0];
+    dmx_ctx *c = r0.ctx;
+    HIPCHK(hipSetDevice(r0.dev));
+    for (int m = 0; m < M; ++m)
+    {
+        DMXCHK(dmx_ctx_set_model(c, r0.models[(size_t)m]));
+        DMXCHK(dmx_track_overlap_add_planes(c, e->segOut[(size_t)m].p, nseg[(size_t)m], n, shifts[(size_t)m], c->dStats, e->out.p, layout,
+                                            M == 1 ? 0 : 2 * m, M == 1 ? 2 * S : 2));
+    }
+    HIPCHK(hipMemcpyAsync(out, e->out.p, sizeof(float) * (size_t)S * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DMX_OK;
+}

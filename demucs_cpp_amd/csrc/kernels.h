@@ -148,13 +148,20 @@ void launch_track_stats(const float *audio, i64 n, double *partials, int nblk, h
 // stats[0]=mean, stats[1]=std (unbiased) from partials
 void launch_track_stats_final(const double *partials, int nblk, i64 n, float *stats, hipStream_t s);
 // chunk extraction: mixes[i] = segment `segIdx[i]` of the normalised, shifted, zero-padded track,
-// centred in a zero segment (segment_inference, model_apply.cpp:250-288)
+// centred in a zero segment (segment_inference, model_apply.cpp:250-288). segIdx is a HOST array
+// (passed to the kernel by value, kMax per launch).
+struct TrackSegIdx
+{
+    static const int kMax = 64;
+    int v[kMax];
+};
 void launch_track_gather(const float *audio, i64 n, const float *stats, int shiftOffset, i64 seg, i64 stride,
                          i64 len, const int *segIdx, int nIdx, float *mixes, hipStream_t s);
-// overlap-add of nSeg segment outputs [nSeg][S][2][seg] (segment ids 0..nSeg-1) into out.
+// overlap-add of nSeg segment outputs [nSeg][S][2][seg] (segment ids 0..nSeg-1) into planes
+// [planeBase, planeBase + nPlanes) (plane = stem*2 + channel) and samples [i0, i1) of out.
 // layout 0: planar [S][2][n]; layout 1: Eigen column-major image (s + S*(c + 2*i))
 void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len, i64 n, int shiftOffset,
-                      const float *stats, float *out, int layout, hipStream_t s);
+                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s);
 // interleaved <-> planar helpers
 void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream_t s);
 

@@ -298,12 +298,14 @@ void launch_track_stats_final(const double *partials, int nblk, i64 n, float *st
     hipLaunchKernelGGL(track_stats_final_kernel, dim3(1), dim3(64), 0, s, partials, nblk, n, stats);
 }
 
-// shift + zero pad + normalise + chunk + centre (model_apply.cpp:21-43,93-138,189-194,250-262)
+// shift + zero pad + normalise + chunk + centre (model_apply.cpp:21-43,93-138,189-194,250-262).
+// The segment indices travel by value in the kernel arguments: no device index buffer, no host
+// synchronisation between consecutive gathers.
 __global__ __launch_bounds__(256) void track_gather_kernel(const float *audio, i64 n, const float *stats, int shiftOffset,
-                                                           i64 seg, i64 stride, i64 len, const int *segIdx, float *mixes)
+                                                           i64 seg, i64 stride, i64 len, TrackSegIdx segIdx, float *mixes)
 {
     const int which = blockIdx.y;
-    const i64 off = (i64)segIdx[which] * stride;
+    const i64 off = (i64)segIdx.v[which] * stride;
     const i64 chunk = seg < len - off ? seg : len - off;
     const i64 left = (seg - chunk) / 2; // floor(total_padding / 2)
     const float mean = stats[0], stdv = stats[1];
@@ -332,22 +334,33 @@ void launch_track_gather(const float *audio, i64 n, const float *stats, int shif
     int gx = (int)((seg + 255) / 256);
     if (gx > 512)
         gx = 512;
-    hipLaunchKernelGGL(track_gather_kernel, dim3(gx, nIdx), dim3(256), 0, s, audio, n, stats, shiftOffset, seg, stride, len,
-                       segIdx, mixes);
+    for (int i0 = 0; i0 < nIdx; i0 += TrackSegIdx::kMax)
+    {
+        TrackSegIdx t{};
+        const int nb = nIdx - i0 < TrackSegIdx::kMax ? nIdx - i0 : TrackSegIdx::kMax;
+        for (int i = 0; i < nb; ++i)
+            t.v[i] = segIdx[i0 + i];
+        hipLaunchKernelGGL(track_gather_kernel, dim3(gx, nb), dim3(256), 0, s, audio, n, stats, shiftOffset, seg, stride, len, t,
+                           mixes + (i64)i0 * seg * 2);
+    }
 }
 
 // weighted overlap-add in segment order, /sum_weight, trim, de-normalise
 // (model_apply.cpp:171-179,207-246,129-135,88). Each output sample is covered by at most
 // ceil(seg/stride) = 2 segments; they are accumulated in increasing segment index like the
 // reference loop, so the result does not depend on how segments were sharded over GPUs.
+// planes [planeBase, planeBase + gridDim.y) (plane = s*2 + ch) and samples [i0, i1) of the output are
+// produced: the bag takes stem m from model m, and a track can be finished (and copied out) in pieces
+// as soon as the segments covering a piece are done.
 __global__ __launch_bounds__(256) void track_ola_kernel(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len,
-                                                        i64 n, int shiftOffset, const float *stats, float *out, int layout)
+                                                        i64 n, int shiftOffset, const float *stats, float *out, int layout,
+                                                        int planeBase, i64 i0, i64 i1)
 {
-    const int plane = blockIdx.y; // s*2 + ch
+    const int plane = blockIdx.y + planeBase;
     const float mean = stats[0], stdv = stats[1];
     const i64 maxShift = 22050;
     const float half = (float)(seg / 2);
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
+    for (i64 i = i0 + (i64)blockIdx.x * 256 + threadIdx.x; i < i1; i += (i64)gridDim.x * 256)
     {
         const i64 j = i + maxShift - shiftOffset; // position in the shifted track
         float acc = 0.f, sw = 0.f;
@@ -379,13 +392,15 @@ __global__ __launch_bounds__(256) void track_ola_kernel(const float *segOut, int
     }
 }
 void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len, i64 n, int shiftOffset,
-                      const float *stats, float *out, int layout, hipStream_t s)
+                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s)
 {
-    int gx = (int)((n + 255) / 256);
+    if (i1 <= i0 || nPlanes <= 0)
+        return;
+    int gx = (int)((i1 - i0 + 255) / 256);
     if (gx > 4096)
         gx = 4096;
-    hipLaunchKernelGGL(track_ola_kernel, dim3(gx, S * 2), dim3(256), 0, s, segOut, nSeg, S, seg, stride, len, n, shiftOffset,
-                       stats, out, layout);
+    hipLaunchKernelGGL(track_ola_kernel, dim3(gx, nPlanes), dim3(256), 0, s, segOut, nSeg, S, seg, stride, len, n, shiftOffset,
+                       stats, out, layout, planeBase, i0, i1);
 }
 
 __global__ void planar_to_interleaved_kernel(const float *src, float *dst, i64 n)

@@ -5,8 +5,8 @@ is embarrassingly parallel: every iteration reads a slice of the shifted track a
 independent (S, 2, segment) block; the only coupling is the weighted overlap-add. So:
 
   * every rank holds the weights and the (small) input track;
-  * segment g is owned by rank g % world (all segments cost the same: short tails are
-    zero-padded to a full segment, Q8);
+  * rank r owns the contiguous segment range [r*n_seg/world, (r+1)*n_seg/world) (all segments cost the
+    same: short tails are zero-padded to a full segment, Q8) - the dealing of csrc/engine.cpp;
   * each rank runs its segments through the hot path in batches;
   * ONE exchange step: the per-segment outputs are gathered to the root (RCCL gather over xGMI;
     11 MB per 4-source segment), equal-sized slabs padded to ceil(n_seg/world) segments;
@@ -24,7 +24,9 @@ import torch
 
 
 def owned_segments(n_segments: int, rank: int, world: int) -> List[int]:
-    return list(range(rank, n_segments, world))
+    """Contiguous balanced ranges, the dealing of csrc/engine.cpp (dmx_engine_partition): rank r owns
+    segments [r*n/world, (r+1)*n/world) - one contiguous slab of results per rank."""
+    return list(range(rank * n_segments // world, (rank + 1) * n_segments // world))
 
 
 def slab_size(n_segments: int, world: int) -> int:
@@ -93,9 +95,8 @@ def track_infer_sharded(backend, audio_il: torch.Tensor, shift: int, dist=None, 
         dist.gather(local, gathered, dst=root)
         if rank != root:
             return None
-        # slab r, slot j holds segment r + j*world  ->  restore segment order
-        stacked = torch.stack(gathered, dim=1)  # [slab][world][S][2][seg]
-        all_seg = stacked.reshape(slab * world, S, 2, seg)[:n_seg].contiguous()
+        # slab r holds segments [r*n_seg/world, (r+1)*n_seg/world) in its first slots -> segment order
+        all_seg = torch.cat([gathered[r][:len(owned_segments(n_seg, r, world))] for r in range(world)], dim=0)
     else:
         all_seg = local[:n_seg]
     return backend.overlap_add(all_seg, n_seg, n, shift, stats)

@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <functional>
 #include <iostream>
+#include <algorithm>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -64,58 +66,65 @@ struct StemTensor
     float operator()(int s, int c, int64_t i) const { return data[(size_t)(s + (int64_t)S * (c + 2 * i))]; }
 };
 
-// weight container: resident in HBM behind an opaque handle (src/model.hpp:285-554)
+// weight container: resident in HBM (on every device of the engine) behind an opaque handle
+// (src/model.hpp:285-554). One engine = weights + activation arena(s) + streams; see include/demucs_hip.h.
+//
+// Re-entrancy: the reference's contract is concurrent demucs_inference calls on ONE shared const model
+// (cli-apps/threaded_inference.hpp:105-123 runs N std::threads on it). Calls on one demucs_model are
+// serialised here by `lock` (one GPU context already keeps every CU busy, so nothing is lost); results are
+// bit-identical to sequential calls. tests/threaded_harness.cpp runs exactly that pattern.
 struct demucs_model
 {
     bool is_4sources = true;
-    int device = 0;          // HIP device the weights live on (env DMX_DEVICE at load time)
-    int shift_offset = -1;   // -1: rand() % 22050 like src/model_apply.cpp:114; else fixed
-    int max_batch = 12;      // segments in flight per context (7.8 GB of arena; 3.4 ms per segment vs 4.1 at 4)
-    dmx_model *handle = nullptr;
-    mutable dmx_ctx *ctx = nullptr; // lazily created, reused across calls (one per model object)
+    std::vector<int> devices;  // HIP devices (env DMX_DEVICES="0,1,..."; "all"; default: device DMX_DEVICE or 0)
+    int shift_offset = -1;     // -1: rand() % 22050 like src/model_apply.cpp:114; else fixed
+    int max_batch = 12;        // segments in flight per device (7.8 GB of arena; 3.4 ms per segment vs 4.1 at 4)
+    dmx_engine *engine = nullptr;
+    mutable std::mutex lock;
     demucs_model() {}
     demucs_model(const demucs_model &) = delete;
     demucs_model &operator=(const demucs_model &) = delete;
     ~demucs_model()
     {
-        if (ctx)
-            dmx_ctx_free(ctx);
-        if (handle)
-            dmx_model_free(handle);
+        if (engine)
+            dmx_engine_free(engine);
     }
 };
 
-// src/model.hpp:649-650. Returns false and reports on stderr exactly when the reference
-// loader does (src/model_load.cpp:64-69,97-102,1065-1070,1096-1105), and additionally
-// when no HIP device is usable (there is no CPU fallback).
-inline bool load_demucs_model(const std::string &model_file, demucs_model *model)
-{
-    const char *dev = std::getenv("DMX_DEVICE");
-    model->device = dev ? std::atoi(dev) : model->device;
-    if (const char *so = std::getenv("DMX_SHIFT_OFFSET"))
-        model->shift_offset = std::atoi(so);
-    if (const char *mb = std::getenv("DMX_BATCH"))
-        model->max_batch = std::max(1, std::atoi(mb));
-    if (dmx_model_load(model_file.c_str(), model->device, &model->handle) != DMX_OK)
-    {
-        std::cerr << "load_demucs_model: " << dmx_last_error() << std::endl;
-        return false;
-    }
-    model->is_4sources = dmx_model_n_sources(model->handle) == 4;
-    return true;
-}
-
 namespace detail
 {
-inline dmx_ctx *context(const demucs_model &m)
+// DMX_DEVICES: comma-separated HIP device ids, or "all"; DMX_DEVICE: one id (kept from round 1)
+inline std::vector<int> devices_from_env()
 {
-    if (!m.ctx && dmx_ctx_create(m.handle, 0, m.max_batch, &m.ctx) != DMX_OK)
+    std::vector<int> d;
+    if (const char *e = std::getenv("DMX_DEVICES"))
     {
-        // the reference has no error channel in inference (std::exit(1), src/layers.cpp:98-103)
-        std::cerr << "demucs_inference: " << dmx_last_error() << std::endl;
-        std::exit(1);
+        std::string s(e);
+        if (s == "all")
+        {
+            for (int i = 0; i < dmx_device_count(); ++i)
+                d.push_back(i);
+            return d;
+        }
+        std::stringstream ss(s);
+        std::string tok;
+        while (std::getline(ss, tok, ','))
+            if (!tok.empty())
+                d.push_back(std::atoi(tok.c_str()));
     }
-    return m.ctx;
+    if (d.empty())
+    {
+        const char *one = std::getenv("DMX_DEVICE");
+        d.push_back(one ? std::atoi(one) : 0);
+    }
+    return d;
+}
+inline void read_env(int &shift_offset, int &max_batch)
+{
+    if (const char *so = std::getenv("DMX_SHIFT_OFFSET"))
+        shift_offset = std::atoi(so);
+    if (const char *mb = std::getenv("DMX_BATCH"))
+        max_batch = std::max(1, std::atoi(mb));
 }
 struct CbThunk
 {
@@ -127,20 +136,99 @@ inline void progress_thunk(float p, const char *msg, void *user)
     if (cb && *cb)
         (*cb)(p, std::string(msg));
 }
+[[noreturn]] inline void die(const char *where)
+{
+    // the reference has no error channel in inference (std::exit(1), src/layers.cpp:98-103)
+    std::cerr << where << ": " << dmx_last_error() << std::endl;
+    std::exit(1);
+}
 } // namespace detail
 
-// src/model.hpp:658-660, src/model_apply.cpp:60-91
+// src/model.hpp:649-650. Returns false and reports on stderr exactly when the reference
+// loader does (src/model_load.cpp:64-69,97-102,1065-1070,1096-1105), and additionally
+// when no HIP device is usable (there is no CPU fallback).
+inline bool load_demucs_model(const std::string &model_file, demucs_model *model)
+{
+    if (model->devices.empty())
+        model->devices = detail::devices_from_env();
+    detail::read_env(model->shift_offset, model->max_batch);
+    const char *files[1] = {model_file.c_str()};
+    if (dmx_engine_create(files, 1, model->devices.data(), (int)model->devices.size(), model->max_batch, DMX_TRANSPORT_AUTO,
+                          &model->engine) != DMX_OK)
+    {
+        std::cerr << "load_demucs_model: " << dmx_last_error() << std::endl;
+        return false;
+    }
+    model->is_4sources = dmx_engine_n_sources(model->engine) == 4;
+    return true;
+}
+
+// src/model.hpp:658-660, src/model_apply.cpp:60-91. With several devices the overlapping-segment loop is
+// sharded over them (csrc/engine.cpp); the result is bit-identical to one device.
 inline StemTensor demucs_inference(const demucs_model &model, const StereoMatrix &full_audio, ProgressCallback cb)
 {
     const int S = model.is_4sources ? 4 : 6;
     StemTensor out(S, full_audio.cols());
     detail::CbThunk th{&cb};
-    if (dmx_track_infer(detail::context(model), full_audio.data.data(), full_audio.cols(), model.shift_offset, out.data.data(),
-                        DMX_LAYOUT_EIGEN, detail::progress_thunk, &th) != DMX_OK)
+    std::lock_guard<std::mutex> guard(model.lock);
+    if (dmx_engine_track_infer(model.engine, full_audio.data.data(), full_audio.cols(), &model.shift_offset, out.data.data(),
+                               DMX_LAYOUT_EIGEN, detail::progress_thunk, &th) != DMX_OK)
+        detail::die("demucs_inference");
+    return out;
+}
+
+// The fine-tuned bag (cli-apps/demucs_ft.cpp:136-241): four 4-source models, stem i from model i. The
+// reference runs four demucs_inference calls back to back; calling demucs_inference on four demucs_model
+// objects still works here, but one bag engine deals all (model, segment) items over the devices at once
+// (168 items on 8 GPUs = 21 each, instead of four rounds of 42 = 6 + 6 + 5 + ...).
+struct demucs_ft_bag
+{
+    std::vector<int> devices;
+    int shift_offsets[4] = {-1, -1, -1, -1}; // -1: successive rand() % 22050 draws, like four demucs_inference calls
+    int max_batch = 12;
+    dmx_engine *engine = nullptr;
+    mutable std::mutex lock;
+    demucs_ft_bag() {}
+    demucs_ft_bag(const demucs_ft_bag &) = delete;
+    demucs_ft_bag &operator=(const demucs_ft_bag &) = delete;
+    ~demucs_ft_bag()
     {
-        std::cerr << "demucs_inference: " << dmx_last_error() << std::endl;
-        std::exit(1);
+        if (engine)
+            dmx_engine_free(engine);
     }
+};
+// model_files: drums, bass, other, vocals (the order of cli-apps/demucs_ft.cpp:141-168)
+inline bool load_demucs_ft_bag(const std::vector<std::string> &model_files, demucs_ft_bag *bag)
+{
+    if (model_files.size() != 4)
+    {
+        std::cerr << "load_demucs_ft_bag: four model files are required" << std::endl;
+        return false;
+    }
+    if (bag->devices.empty())
+        bag->devices = detail::devices_from_env();
+    int so = -1;
+    detail::read_env(so, bag->max_batch);
+    if (so >= 0)
+        for (int &v : bag->shift_offsets)
+            v = so;
+    const char *files[4] = {model_files[0].c_str(), model_files[1].c_str(), model_files[2].c_str(), model_files[3].c_str()};
+    if (dmx_engine_create(files, 4, bag->devices.data(), (int)bag->devices.size(), bag->max_batch, DMX_TRANSPORT_AUTO, &bag->engine) !=
+        DMX_OK)
+    {
+        std::cerr << "load_demucs_ft_bag: " << dmx_last_error() << std::endl;
+        return false;
+    }
+    return true;
+}
+inline StemTensor demucs_ft_inference(const demucs_ft_bag &bag, const StereoMatrix &full_audio, ProgressCallback cb)
+{
+    StemTensor out(4, full_audio.cols());
+    detail::CbThunk th{&cb};
+    std::lock_guard<std::mutex> guard(bag.lock);
+    if (dmx_engine_track_infer(bag.engine, full_audio.data.data(), full_audio.cols(), bag.shift_offsets, out.data.data(), DMX_LAYOUT_EIGEN,
+                               detail::progress_thunk, &th) != DMX_OK)
+        detail::die("demucs_ft_inference");
     return out;
 }
 
@@ -161,41 +249,73 @@ struct stft_buffers // kept for signature compatibility (src/dsp.hpp:20-101); th
     explicit stft_buffers(int /*n_samples*/) {}
 };
 
-// src/model.hpp:662-666, src/model_inference.cpp:48-475
-inline void model_inference(const demucs_model &model, demucs_segment_buffers &buffers, stft_buffers & /*stft_buf*/,
-                            ProgressCallback cb, float current_progress, float segment_progress)
+namespace detail
 {
-    if (buffers.segment_samples != DMX_SEGMENT_SAMPLES)
+inline void segment_call(const demucs_model &model, int segment_samples, const float *mix, float *targets_out, const ProgressCallback &cb,
+                         float current_progress, float segment_progress)
+{
+    if (segment_samples != DMX_SEGMENT_SAMPLES)
     {
         std::cerr << "model_inference: segment must be " << DMX_SEGMENT_SAMPLES << " samples" << std::endl;
         std::exit(1);
     }
     if (cb)
-        cb(current_progress, "3., apply_model mix shape: (2, " + std::to_string(buffers.segment_samples) + ")");
-    if (dmx_segment_infer(detail::context(model), buffers.mix.data.data(), buffers.targets_out.data.data(), DMX_LAYOUT_EIGEN) !=
-        DMX_OK)
+        cb(current_progress, "3., apply_model mix shape: (2, " + std::to_string(segment_samples) + ")");
     {
-        std::cerr << "model_inference: " << dmx_last_error() << std::endl;
-        std::exit(1);
+        std::lock_guard<std::mutex> guard(model.lock);
+        dmx_ctx *ctx = dmx_engine_root_ctx(model.engine, 0);
+        if (!ctx || dmx_segment_infer(ctx, mix, targets_out, DMX_LAYOUT_EIGEN) != DMX_OK)
+            die("model_inference");
     }
     if (cb)
         cb(current_progress + segment_progress, "Mask + istft");
 }
+} // namespace detail
+
+// src/model.hpp:662-666, src/model_inference.cpp:48-475
+inline void model_inference(const demucs_model &model, demucs_segment_buffers &buffers, stft_buffers & /*stft_buf*/,
+                            ProgressCallback cb, float current_progress, float segment_progress)
+{
+    detail::segment_call(model, buffers.segment_samples, buffers.mix.data.data(), buffers.targets_out.data.data(), cb, current_progress,
+                         segment_progress);
+}
 
 #ifdef DEMUCSCPP_HIP_WITH_EIGEN
-// Exact reference signatures (zero-copy in, one copy out).
-inline Eigen::Tensor<float, 3> demucs_inference(const demucs_model &model, const Eigen::MatrixXf &full_audio, ProgressCallback cb)
+// Exact reference signatures on the Eigen types themselves (zero-copy in, written in place out): a
+// caller that keeps /root/reference/src/model.hpp:569-666 as it is compiles against these.
+typedef Eigen::Tensor<float, 3> Tensor3dXf; // src/tensor.hpp
+
+inline Tensor3dXf demucs_inference(const demucs_model &model, const Eigen::MatrixXf &full_audio, ProgressCallback cb)
 {
     const int S = model.is_4sources ? 4 : 6;
-    Eigen::Tensor<float, 3> out(S, 2, full_audio.cols());
+    Tensor3dXf out(S, 2, full_audio.cols());
     detail::CbThunk th{&cb};
-    if (dmx_track_infer(detail::context(model), full_audio.data(), full_audio.cols(), model.shift_offset, out.data(),
-                        DMX_LAYOUT_EIGEN, detail::progress_thunk, &th) != DMX_OK)
-    {
-        std::cerr << "demucs_inference: " << dmx_last_error() << std::endl;
-        std::exit(1);
-    }
+    std::lock_guard<std::mutex> guard(model.lock);
+    if (dmx_engine_track_infer(model.engine, full_audio.data(), full_audio.cols(), &model.shift_offset, out.data(), DMX_LAYOUT_EIGEN,
+                               detail::progress_thunk, &th) != DMX_OK)
+        detail::die("demucs_inference");
     return out;
+}
+
+// src/model.hpp:569-647: the boundary members with the reference's names and types. The reference's
+// intermediates (x, xt, saved_*, ... :583-647) live in the HBM arena and have no host image.
+struct demucs_segment_buffers_eigen
+{
+    int segment_samples;
+    Eigen::MatrixXf mix;     // (nb_channels, segment_samples)
+    Tensor3dXf targets_out;  // (nb_sources, nb_channels, segment_samples)
+    demucs_segment_buffers_eigen(int nb_channels, int segment_samples_, int nb_sources)
+        : segment_samples(segment_samples_), mix(nb_channels, segment_samples_), targets_out(nb_sources, nb_channels, segment_samples_)
+    {
+        mix.setZero();
+        targets_out.setZero();
+    }
+};
+inline void model_inference(const demucs_model &model, demucs_segment_buffers_eigen &buffers, stft_buffers & /*stft_buf*/,
+                            ProgressCallback cb, float current_progress, float segment_progress)
+{
+    detail::segment_call(model, buffers.segment_samples, buffers.mix.data(), buffers.targets_out.data(), cb, current_progress,
+                         segment_progress);
 }
 #endif
 

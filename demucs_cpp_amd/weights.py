@@ -112,31 +112,56 @@ def tensor_catalogue(n_sources: int = 4) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
-def synth_weights(n_sources: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+def synth_weights(n_sources: int = 4, seed: int = 0, variant: str = "default") -> Dict[str, np.ndarray]:
     """Synthetic fp16 weights: N(0, 1/fan_in) for linear /
     conv kernels, norm weights 1 +- 0.1, biases 0.01 N(0,1), LayerScale tensors
-    U(0.05, 0.5) so that every residual branch moves the output measurably."""
+    U(0.05, 0.5) so that every residual branch moves the output measurably.
+
+    Stress variants (parity where the default model is blind, tests/test_gpu_parity.py):
+      "dc"       every conv / linear bias = 3 + 0.5 N(0,1) and norm biases N(0,1), norm weights U(0.2, 3):
+                 the inputs of GroupNorm / LayerNorm have |mean| >> sigma, which is where a one-pass
+                 sum / sum-of-squares variance loses digits against the reference's two-pass
+                 calculate_variance (/root/reference/src/layers.hpp:76-95);
+      "illcond"  "dc" + every DConv 1x1 weight (`.3.weight`, 2C x C/8) rebuilt with singular values from 1
+                 down to 1e-3 and the last quarter exactly 0 (rank deficient): exercises the factored
+                 W^T W statistics of the DConv (csrc/model_pack.cpp, EPI_STATS_FACT);
+      "initscale" LayerScale tensors = 1e-4, the value Demucs initialises them with."""
+    assert variant in ("default", "dc", "illcond", "initscale")
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
+    dc = variant in ("dc", "illcond")
     for name, shape in tensor_catalogue(n_sources):
         n = int(np.prod(shape))
         if name.endswith(".scale"):
             a = rng.uniform(0.05, 0.5, size=shape)
+            if variant == "initscale":
+                a = np.full(shape, 1e-4)
         elif name == "freq_emb.embedding.weight":
             a = 0.5 * rng.standard_normal(shape)
         elif name.endswith("bias") or name.endswith("in_proj_bias"):
-            if ".norm" in name or ".1.bias" in name or ".4.bias" in name:
-                a = 0.05 * rng.standard_normal(shape)
+            is_norm = ".norm" in name or ".1.bias" in name or ".4.bias" in name
+            if is_norm:
+                a = (1.0 if dc else 0.05) * rng.standard_normal(shape)
             else:
                 a = 0.01 * rng.standard_normal(shape)
+                if dc:
+                    a = 3.0 + 0.5 * rng.standard_normal(shape)
         elif ".norm" in name or name.endswith(".1.weight") or name.endswith(".4.weight"):
             a = 1.0 + 0.1 * rng.standard_normal(shape)
+            if dc:
+                a = rng.uniform(0.2, 3.0, size=shape)
         else:
             if "conv_tr" in name:
                 fan_in = 2 * shape[0]  # every output sample sees 2 taps x Cin
             else:
                 fan_in = n // shape[0]
             a = rng.standard_normal(shape) / np.sqrt(float(fan_in))
+            if variant == "illcond" and ".dconv." in name and name.endswith(".3.weight"):
+                rows, cols = shape[0], int(np.prod(shape[1:]))
+                u, _, vt = np.linalg.svd(rng.standard_normal((rows, cols)), full_matrices=False)
+                sv = np.logspace(0, -3, cols)
+                sv[cols - cols // 4:] = 0.0
+                a = ((u * sv) @ vt).reshape(shape) * np.sqrt(float(rows) / max(1, cols - cols // 4)) / np.sqrt(float(fan_in)) * 3.0
         out[name] = np.ascontiguousarray(a.astype(np.float16))
     return out
 
@@ -180,5 +205,5 @@ def read_model(path: str) -> Tuple[int, Dict[str, np.ndarray]]:
     return ns, out
 
 
-def write_synthetic_model(path: str, n_sources: int = 4, seed: int = 0) -> None:
-    write_model(path, synth_weights(n_sources, seed), n_sources)
+def write_synthetic_model(path: str, n_sources: int = 4, seed: int = 0, variant: str = "default") -> None:
+    write_model(path, synth_weights(n_sources, seed, variant), n_sources)

@@ -10,7 +10,7 @@
  * Conventions: plain C, opaque handles, int status (0 = DMX_OK), no exceptions or C++
  * types across the ABI, dmx_last_error() gives the message of the last failure on the
  * calling thread. All audio is fp32, 44.1 kHz, stereo. A context is NOT thread-safe;
- * create one context per host thread / stream (the model handle is immutable after load
+ * create one context per host thread / stream, or use a dmx_engine, which serialises internally (the model handle is immutable after load
  * and may be shared, like the reference's `const demucs_model&`).
  *
  * There is NO CPU fallback: every entry point that computes fails with
@@ -82,6 +82,9 @@ extern "C"
      * The context synchronises its current stream before switching. (No reference counterpart:
      * the Eigen path is synchronous host code.) */
     int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream);
+    /* Rebind the context to another model of the same architecture on the same device (the arena and the
+     * plan are shared; the four fine-tuned models of demucs_ft.cpp:136-184 run through one context). */
+    int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m);
 
     /* Replaces demucscpp::model_inference (src/model.hpp:662-666,
      * src/model_inference.cpp:48): one full segment, host pointers.
@@ -122,6 +125,42 @@ extern "C"
      *    d_seg_out [n_segments][S][2][segment_samples]; d_out S x 2 x n in `layout`     */
     int dmx_track_overlap_add_device(dmx_ctx *c, const float *d_seg_out, int n_segments, int64_t n, int shift_offset,
                                      const float *d_stats, float *d_out, int layout);
+
+    /* ---- several GPUs and / or a bag of models in ONE process (csrc/engine.cpp) ----------------------
+     * Replaces the loop nest "for each model of the bag (cli-apps/demucs_ft.cpp:221-241): for each
+     * overlapping segment (src/model_apply.cpp:189-235)": the (model, segment) work items are dealt in
+     * contiguous, balanced ranges to the devices, every device runs its items on its own host thread and
+     * stream, the per-item outputs are gathered to the root device over xGMI (RCCL send/recv, or SDMA
+     * peer copies), and the root overlap-adds each model's segments in segment order - bit-identical to
+     * dmx_track_infer on one device. n_models == 1: plain demucs_inference. n_models > 1 (= number of
+     * sources): the fine-tuned bag, stem i of the result is stem i of model i (demucs_ft.cpp:238-241).
+     *   devices / n_devices : HIP device ids (n_devices <= 0: all visible devices). The same id may be
+     *                         listed more than once (several logical devices on one GPU; P2P transport only).
+     *   transport           : DMX_TRANSPORT_AUTO = env DMX_GATHER ("rccl" / "p2p"), else RCCL when there
+     *                         are >= 2 distinct devices, else P2P.
+     * An engine serialises concurrent dmx_engine_track_infer calls internally (the reference's threaded
+     * driver calls demucs_inference concurrently on one const model, threaded_inference.hpp:105-123).  */
+#define DMX_TRANSPORT_AUTO 0
+#define DMX_TRANSPORT_RCCL 1
+#define DMX_TRANSPORT_P2P 2
+    typedef struct dmx_engine dmx_engine;
+    int dmx_engine_create(const char *const *model_files, int n_models, const int *devices, int n_devices, int max_batch,
+                          int transport, dmx_engine **out);
+    void dmx_engine_free(dmx_engine *e);
+    int dmx_engine_n_devices(const dmx_engine *e);
+    int dmx_engine_n_models(const dmx_engine *e);
+    int dmx_engine_n_sources(const dmx_engine *e);
+    int dmx_engine_transport(const dmx_engine *e);
+    /* the root device's context bound to model `model` (segment-level calls: dmx_segment_infer*) */
+    dmx_ctx *dmx_engine_root_ctx(dmx_engine *e, int model);
+    /* shift_offsets: one per model (NULL or -1 entries: rand() % 22050 drawn in model order, like the
+     * reference's successive demucs_inference calls); audio 2 x n, out S x 2 x n, both `layout`. */
+    int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t n, const int *shift_offsets, float *out, int layout,
+                               dmx_progress_fn progress, void *user);
+
+    /* the dealing of (model, segment) items used by dmx_engine_track_infer (pure host function):
+     * runs_out[(l*n_models + m)*2 + {0,1}] = segment range [g0, g1) of model m owned by device l */
+    int dmx_engine_partition(const int *n_segments, int n_models, int n_devices, int *runs_out);
 
     /* ---- debug taps (layer-level parity tests, cf. the reference's print-only layer tests
      * test/test_layers.cpp:1390-2157): copies a named intermediate activation of the last

@@ -87,9 +87,17 @@ def _worker(rank, world, port, n, shift, q):
 
 
 def test_ownership_and_slabs():
-    assert owned_segments(7, 0, 2) == [0, 2, 4, 6] and owned_segments(7, 1, 2) == [1, 3, 5]
+    assert owned_segments(7, 0, 2) == [0, 1, 2] and owned_segments(7, 1, 2) == [3, 4, 5, 6]  # contiguous, balanced
     assert slab_size(7, 2) == 4 and slab_size(42, 8) == 6
-    assert sorted(sum((owned_segments(42, r, 8) for r in range(8)), [])) == list(range(42))
+    assert sum((owned_segments(42, r, 8) for r in range(8)), []) == list(range(42))
+    assert sorted(len(owned_segments(42, r, 8)) for r in range(8)) == [5] * 6 + [6] * 2
+    # the same dealing as the in-process engine (csrc/engine.cpp, dmx_engine_partition)
+    from demucs_cpp_amd import binding
+    for n_seg, world in ((42, 8), (7, 2), (3, 8), (41, 5)):
+        runs = binding.engine_partition([n_seg], world)
+        for r in range(world):
+            own = owned_segments(n_seg, r, world)
+            assert runs[r] == ([(0, own[0], own[-1] + 1)] if own else [])
 
 
 @pytest.mark.parametrize("n,shift", [(3 * SEG + 777, 4033), (SEG // 3, 12436)])
