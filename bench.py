@@ -253,14 +253,17 @@ def main():
     # BASELINE.json configs[1] read literally: ONE segment per call (latency), device resident
     single_ms = None
     if rank == 0 and world == 1 and not args.no_single:
-        for _ in range(2):
+        torch.cuda.synchronize()
+        ctx.set_stream(None)  # the context's own stream: repeated identical calls replay a captured HIP graph
+        for _ in range(3):
             ctx.segment_device(mix.data_ptr(), out.data_ptr(), 1)
         ctx.synchronize()
         t1 = time.perf_counter()
         for _ in range(10):
             ctx.segment_device(mix.data_ptr(), out.data_ptr(), 1)
-        ctx.synchronize()
+            ctx.synchronize()  # latency of ONE call: wait for every result before the next call
         single_ms = (time.perf_counter() - t1) / 10 * 1e3
+        ctx.set_stream(stream.cuda_stream)
 
     # ---- BASELINE configs[2]: a 4-minute track end to end (host buffers in and out), and the same track
     # strong-scaled over the ranks (segments dealt in contiguous ranges, RCCL gather, root overlap-add)

@@ -23,6 +23,17 @@
 #include "kernels.h"
 #include <cstdlib>
 
+// Ablation switches for diagnostic builds (results wrong by construction; never set in the product build)
+#ifndef DMX_ABL_ATT_NOSM
+#define DMX_ABL_ATT_NOSM 0 // no softmax arithmetic
+#endif
+#ifndef DMX_ABL_ATT_NOSTAGE
+#define DMX_ABL_ATT_NOSTAGE 0 // no K/V staging inside the tile loop
+#endif
+#ifndef DMX_ABL_ATT_NOV
+#define DMX_ABL_ATT_NOV 0 // no V fragment reads
+#endif
+
 namespace dmx
 {
 
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     int cur = 0;
     for (int t = 0; t < nt; ++t)
     {
-        load_tile((t + 1) * KT); // beyond the end: clamped re-read, never stored
+        if (!DMX_ABL_ATT_NOSTAGE)
+            load_tile((t + 1) * KT); // beyond the end: clamped re-read, never stored
         // ---- S^T = K Q^T : 4 key fragments x QF query fragments; dim step outermost so that
         // consecutive MFMAs hit different accumulators
         f32x4 sT[QF][4];
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
         }
         // ---- online softmax for query (f, l15); lane holds keys 16kf + 4h4 + r
 #pragma unroll
-        for (int f = 0; f < QF; ++f)
+        for (int f = 0; f < QF && !DMX_ABL_ATT_NOSM; ++f)
         {
             if (t == nt - 1 && partial) // uniform: only the last tile of a Tk that is not a multiple of 64
             {
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
             for (int d = 0; d < DF; ++d)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    vv[d][c] = Vs[cur][16 * kf + 4 * h4 + c][16 * d + l15];
+                    vv[d][c] = DMX_ABL_ATT_NOV ? qf[0][d].x + (float)c : Vs[cur][16 * kf + 4 * h4 + c][16 * d + l15];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
                     for (int f = 0; f < QF; ++f)
                         o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
         }
-        if (t + 1 < nt)
+        if (t + 1 < nt && !DMX_ABL_ATT_NOSTAGE)
             store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;

@@ -36,6 +36,25 @@
 #define DMX_CFG2_KS 2
 #endif
 
+// Ablation switches for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_ABL_..."`): they remove one
+// ingredient of the interleaved K loop / the epilogue so that its cost can be read off a per-op profile.
+// The results of such a build are WRONG by construction; never set in the product build.
+#ifndef DMX_ABL_NOLOAD
+#define DMX_ABL_NOLOAD 0 // no global loads inside the K loop
+#endif
+#ifndef DMX_ABL_NOSTORE
+#define DMX_ABL_NOSTORE 0 // no ds_write inside the K loop
+#endif
+#ifndef DMX_ABL_NOBAR
+#define DMX_ABL_NOBAR 0 // no barrier inside the K loop
+#endif
+#ifndef DMX_ABL_NOEPI
+#define DMX_ABL_NOEPI 0 // epilogue = one float per lane
+#endif
+#ifndef DMX_ABL_NOADDR
+#define DMX_ABL_NOADDR 0 // no address updates inside the K loop
+#endif
+
 namespace dmx
 {
 
@@ -473,22 +492,26 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a0, b0, c);
-                store_piece(cur ^ 1, c);
-                addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
+                if (!DMX_ABL_NOSTORE)
+                    store_piece(cur ^ 1, c);
+                if (!DMX_ABL_NOADDR)
+                    addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
                 if (c == 1)
                     read_frags(cur, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
                 if (c == 3)
                     maskHeld = maskNext; // tile kt+1 is written out: from here on the validity of tile kt+2
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            if (!DMX_ABL_NOBAR)
+                __syncthreads();
             // k-chunk 1  |  global loads of tile kt+2 into the registers just written out, the first
             // fragments of tile kt+1
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a1, b1, c);
-                load_piece(c);
+                if (!DMX_ABL_NOLOAD)
+                    load_piece(c);
                 if (c == 2)
                     read_frags(cur ^ 1, 0, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -540,6 +563,27 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     }
 #endif
 
+#if DMX_ABL_NOEPI
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            t += aReg[i][0];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            t += bReg[i][0];
+        if (m0 + (tid >> 1) < p.M && n0 + 1 < p.N && EPI != EPI_TRCONV && EPI != EPI_STATS_ONLY && EPI != EPI_STATS_FACT)
+            p.Y[(m0 + (tid >> 1)) * p.ldy + (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES ? n0 / 2 : n0) + (tid & 1)] = t;
+        else if (t == 123.456f)
+            p.Y[0] = t;
+        return;
+    }
+#endif
     // ------------------------------------------------------------------ epilogue
     // The MFMAs were issued with the operands swapped (weights as A, activations as B), so each
     // accumulator holds C^T: lane (l15, kq) owns row m = tile row 16 i + l15 and the 4 CONSECUTIVE

@@ -3,6 +3,7 @@
 #pragma once
 #include "plan.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace dmx
 {
@@ -123,6 +124,7 @@ struct AttnArgs
     unsigned nQt; // query tiles per (batch, head) (filled by launch_attention)
     int xcdMap;   // 1: all query tiles of one (batch, head) on ONE XCD (its K/V stay in that XCD's L2)
 };
+
 void launch_attention(const AttnArgs &a, hipStream_t s);
 
 struct IstftArgs
