@@ -18,10 +18,16 @@
 // Workgroup = 4 waves x (16*QF) queries. K/V tiles of 64 keys are fetched with float4 loads one
 // tile ahead into registers and double-buffered in LDS:
 //   K image  [dim-quad q][key ^ 2(q&3)] float4  -> conflict-free ds_read_b128 of A fragments
-//   V image  [key][HS + 4] floats (row padded by 4) -> V^T A-fragment = 4 ds_read_b32 with lanes on
-//            consecutive dims; the 4-float pad puts keys 4h and 4h+4 on disjoint bank halves.
+//   V image  [key-quad][dim'] float4 (TRANSPOSED while staging: a thread loads the same dim-quad of 4
+//            consecutive keys and writes, per dim, the 4 keys as one float4 - the 4x4 transpose is register
+//            renaming) -> V^T A-fragment (dim = lane&15, keys 4*(lane>>4)+c) = ONE ds_read_b128 (was 4
+//            ds_read_b32). dim' = dim ^ ((dim >> 3) & 3) keeps the 8-lane write groups conflict-free; reads of
+//            16 consecutive dims are conflict-free under any permutation inside aligned groups of 4.
+// Online softmax: row maxima / sums cross the 4 lanes of a query with v_permlane16_swap / v_permlane32_swap (VALU)
+// instead of two LDS round trips (ds_bpermute) in the middle of the dependency chain.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Ablation switches for diagnostic builds (results wrong by construction; never set in the product build)
 #ifndef DMX_ABL_ATT_NOSM
@@ -39,6 +45,29 @@ namespace dmx
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float a4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); } // v_max3_f32
+static constexpr float kDeferLog2 = 16.0f; // exp2-domain threshold of the deferred running maximum
+
+// Reductions over the 4 lanes {l, l^16, l^32, l^48} that hold one query's keys, on the VALU:
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; applied to two copies of x
+// they leave (x[row^1] | x) resp. (x[half^1] | x) side by side.
+__device__ __forceinline__ float quad_lanes_max(float x)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_lanes_sum(float x)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int HS, int QF>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
@@ -47,9 +76,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     constexpr int DF = HS / 16; // dim fragments
     constexpr int KT = 64;      // keys per tile
     constexpr int NL = (KT * DQ) / 256; // float4 loads per thread per tile (K and V each)
-    constexpr int VLD = HS + 4;               // padded V row (floats)
     __shared__ float4 Ks[2][DQ][KT];
-    __shared__ float Vs[2][KT][VLD];
+    __shared__ float4 Vt[2][KT / 4][HS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, h4 = lane >> 4;
@@ -95,9 +123,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     }
 
     // staging: branch-free loads into native vectors; keys beyond Tk re-read the last valid row (their
-    // scores are masked to -inf in the last tile, so P = 0 meets finite V values)
+    // scores are masked to -inf in the last tile, so P = 0 meets finite V values).
+    // K: thread -> (key, dim-quad), NL float4 per tile. V: thread -> (key-quad, dim-quad): the same dim-quad of
+    // 4 consecutive keys (NV = 4 float4 per pass), transposed on the way to LDS.
     static_assert((KT * DQ) % 256 == 0, "whole staging passes");
-    f32x4 kreg[NL], vreg[NL];
+    constexpr int NP = (KT / 4 * DQ + 255) / 256; // V passes per tile (1 for d_h = 64 and 48)
+    f32x4 kreg[NL], vreg[NP][4];
     auto load_tile = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < NL; ++i)
@@ -106,7 +137,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
             const int key = idx / DQ, dq = idx - key * DQ;
             const i64 r = min(t0 + key, p.Tk - 1);
             kreg[i] = *reinterpret_cast<const f32x4 *>(K + r * p.ldk + 4 * dq);
-            vreg[i] = *reinterpret_cast<const f32x4 *>(V + r * p.ldv + 4 * dq);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+        {
+            const int idx = tid + i * 256;
+            const int kq4 = min(idx / DQ, KT / 4 - 1), dq = idx - (idx / DQ) * DQ;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const i64 r = min(t0 + 4 * kq4 + j, p.Tk - 1);
+                vreg[i][j] = *reinterpret_cast<const f32x4 *>(V + r * p.ldv + 4 * dq);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -116,7 +158,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
             const int idx = tid + i * 256;
             const int key = idx / DQ, dq = idx - key * DQ;
             *reinterpret_cast<f32x4 *>(&Ks[buf][dq][key ^ (2 * (dq & 3))]) = kreg[i];
-            *reinterpret_cast<f32x4 *>(&Vs[buf][key][4 * dq]) = vreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+        {
+            const int idx = tid + i * 256;
+            const int kq4 = idx / DQ, dq = idx - kq4 * DQ;
+            if ((KT / 4 * DQ) % 256 == 0 || kq4 < KT / 4)
+            {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) // dim 4 dq + c: keys 4 kq4 .. +3
+                    *reinterpret_cast<f32x4 *>(&Vt[buf][kq4][(4 * dq + c) ^ ((dq >> 1) & 3)]) =
+                        f32x4{vreg[i][0][c], vreg[i][1][c], vreg[i][2][c], vreg[i][3][c]};
+            }
         }
     };
 
@@ -138,38 +192,45 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     store_tile(0);
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t < nt; ++t)
-    {
+    // one key tile; MASK: the (only) tile of a Tk that is not a multiple of 64 - peeled out of the loop so that
+    // the body of the full tiles is one basic block (a uniform branch in the middle would stop the scheduler
+    // from interleaving one fragment's softmax with the other fragment's MFMAs)
+    auto tile = [&](int t, auto maskTag) {
+        constexpr bool MASK = decltype(maskTag)::value;
         if (!DMX_ABL_ATT_NOSTAGE)
             load_tile((t + 1) * KT); // beyond the end: clamped re-read, never stored
-        // ---- S^T = K Q^T : 4 key fragments x QF query fragments; dim step outermost so that
-        // consecutive MFMAs hit different accumulators
+        // ---- S^T = K Q^T (4 key fragments x QF query fragments), softmax per fragment, O^T += V^T P^T.
+        // (Measured alternative, kept out: per-fragment passes S_0 | S_1 + softmax_0 | PV_0 + softmax_1 | PV_1 with the
+        // K / V fragments read twice - the scheduler does interleave each softmax with the other fragment's MFMAs,
+        // but the kernel is 1 % slower than this form: 123.5 vs 124.8 TFLOP/s.)
         f32x4 sT[QF][4];
+        auto scores = [&]() { // both fragments share the K fragments; dim step outermost, consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int f = 0; f < QF; ++f)
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-                sT[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < DF; ++kk)
-        {
-            float4 kv[4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-                kv[kf] = Ks[cur][4 * kk + h4][(16 * kf + l15) ^ (2 * h4)];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int f = 0; f < QF; ++f)
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
+                    sT[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int f = 0; f < QF; ++f)
-                        sT[f][kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c(kv[kf], c), a4c(qf[f][kk], c), sT[f][kf], 0, 0, 0);
-        }
-        // ---- online softmax for query (f, l15); lane holds keys 16kf + 4h4 + r
+            for (int kk = 0; kk < DF; ++kk)
+            {
+                float4 kv[4];
 #pragma unroll
-        for (int f = 0; f < QF && !DMX_ABL_ATT_NOSM; ++f)
-        {
-            if (t == nt - 1 && partial) // uniform: only the last tile of a Tk that is not a multiple of 64
+                for (int kf = 0; kf < 4; ++kf)
+                    kv[kf] = Ks[cur][4 * kk + h4][(16 * kf + l15) ^ (2 * h4)];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int f = 0; f < QF; ++f)
+                            sT[f][kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c(kv[kf], c), a4c(qf[f][kk], c), sT[f][kf], 0, 0, 0);
+            }
+        };
+        // online softmax for query (f, l15); lane holds keys 16kf + 4h4 + r
+        auto softmax = [&](int f) {
+            if (DMX_ABL_ATT_NOSM)
+                return;
+            if constexpr (MASK)
             {
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
@@ -178,65 +239,90 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
                         if (t * KT + 16 * kf + 4 * h4 + r >= p.Tk)
                             sT[f][kf][r] = -INFINITY;
             }
-            float tmax = fmaxf(fmaxf(sT[f][0][0], sT[f][0][1]), fmaxf(sT[f][0][2], sT[f][0][3]));
+            float tmax = max3f(sT[f][0][0], sT[f][0][1], sT[f][0][2]);
+            tmax = max3f(tmax, sT[f][0][3], sT[f][1][0]);
+            float tmx2 = max3f(sT[f][1][1], sT[f][1][2], sT[f][1][3]);
+            tmx2 = max3f(tmx2, sT[f][2][0], sT[f][2][1]);
+            float tmx3 = max3f(sT[f][2][2], sT[f][2][3], sT[f][3][0]);
+            tmx3 = max3f(tmx3, sT[f][3][1], sT[f][3][2]);
+            tmax = max3f(tmax, tmx2, fmaxf(tmx3, sT[f][3][3]));
+            tmax = quad_lanes_max(tmax);
+            float mnew = mrun[f];
+            // The running maximum is raised only when some score of this 16-query fragment exceeds it by more than
+            // 2^16 (wave-uniform per fragment, hence the same decision in the 64- and the 128-query workgroup
+            // shape; always taken on the first tile, mrun = -inf). Otherwise the tile is exponentiated against the
+            // old maximum - in fp32 a common factor <= 2^16 on P and on the row sum costs no accuracy - and the
+            // rescale of O (one exp + 17 multiplies per fragment) is skipped.
+            if (__builtin_amdgcn_ballot_w64(tmax > mnew + kDeferLog2) != 0ull)
+            {
+                mnew = fmaxf(mnew, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
+                lrun[f] *= alpha;
+                mrun[f] = mnew;
 #pragma unroll
-            for (int kf = 1; kf < 4; ++kf)
-                tmax = fmaxf(tmax, fmaxf(fmaxf(sT[f][kf][0], sT[f][kf][1]), fmaxf(sT[f][kf][2], sT[f][kf][3])));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float mnew = fmaxf(mrun[f], tmax);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
-            float psum = 0.f;
+                for (int d = 0; d < DF; ++d)
+                {
+                    o[f][d][0] *= alpha;
+                    o[f][d][1] *= alpha;
+                    o[f][d][2] *= alpha;
+                    o[f][d][3] *= alpha;
+                }
+            }
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                 {
-                    const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: arguments <= 0, underflow to 0 is the right answer
+                    const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: underflow to 0 is the right answer
                     sT[f][kf][r] = pv;
-                    psum += pv;
+                    ps[kf] += pv;
                 }
-            lrun[f] = lrun[f] * alpha + psum;
-            mrun[f] = mnew;
+            lrun[f] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        };
+        // O_f^T += V^T P_f^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c] = one float4 of the V image
+        auto pvprod = [&]() {
 #pragma unroll
-            for (int d = 0; d < DF; ++d)
+            for (int kf = 0; kf < 4; ++kf)
             {
-                o[f][d][0] *= alpha;
-                o[f][d][1] *= alpha;
-                o[f][d][2] *= alpha;
-                o[f][d][3] *= alpha;
-            }
-        }
-        // ---- O^T += V^T P^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c]
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-        {
-            float vv[DF][4];
-#pragma unroll
-            for (int d = 0; d < DF; ++d)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    vv[d][c] = DMX_ABL_ATT_NOV ? qf[0][d].x + (float)c : Vs[cur][16 * kf + 4 * h4 + c][16 * d + l15];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
+                f32x4 vv[DF];
 #pragma unroll
                 for (int d = 0; d < DF; ++d)
+                {
+                    if (DMX_ABL_ATT_NOV)
+                        vv[d] = f32x4{qf[0][d].x, qf[0][d].y, qf[0][d].z, qf[0][d].w};
+                    else
+                        vv[d] = *reinterpret_cast<const f32x4 *>(&Vt[cur][4 * kf + h4][(16 * d + l15) ^ (((16 * d + l15) >> 3) & 3)]);
+                }
 #pragma unroll
-                    for (int f = 0; f < QF; ++f)
-                        o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
-        }
-        if (t + 1 < nt && !DMX_ABL_ATT_NOSTAGE)
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < DF; ++d)
+#pragma unroll
+                        for (int f = 0; f < QF; ++f)
+                            o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
+            }
+        };
+        scores();
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+            softmax(f);
+        pvprod();
+        if (!MASK && !DMX_ABL_ATT_NOSTAGE) // the masked tile is the last one: nothing left to stage
             store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
-    }
+    };
+    const int nfull = partial ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t)
+        tile(t, std::false_type{});
+    if (partial)
+        tile(nt - 1, std::true_type{});
 #pragma unroll
     for (int f = 0; f < QF; ++f)
     {
         // total row sum over the 4 lanes of this query
-        float l = lrun[f];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = quad_lanes_sum(lrun[f]);
         const float inv = 1.0f / l;
         const int qr = q0 + 16 * f + l15;
         if (qr < p.Tq)
