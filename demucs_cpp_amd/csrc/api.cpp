@@ -61,7 +61,10 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
     HIPCHK(hipSetDevice(device));
     // + 256 B: the igemm staging prefetches one K-tile beyond the last one (never used, must be readable)
     HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 256));
-    hipError_t e = hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    // the tail must read as finite numbers (it meets zero activations: 0 x NaN would poison an accumulator)
+    hipError_t e = hipMemset(reinterpret_cast<char *>(m->dW) + m->pm.blob.size() * sizeof(float), 0, 256);
+    if (e == hipSuccess)
+        e = hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         (void)hipFree(m->dW);
@@ -95,7 +98,8 @@ static bool validate_plan(const Plan &p, std::string &why)
             continue;
         const IGemm &g = op.g;
         const bool al = ((i64)g.L0 * g.Cin) % 4 == 0 && (g.stride0 * g.Cin) % 4 == 0 && (g.pad0 * g.Cin) % 4 == 0 &&
-                        g.seg0 % 4 == 0 && g.K % 4 == 0 && g.xBatchStride % 4 == 0 && (g.S1 == 1 || g.seg0 % 16 == 0);
+                        g.seg0 % 4 == 0 && g.K % 4 == 0 && g.xBatchStride % 4 == 0 && (g.S1 == 1 || g.seg0 % 16 == 0) &&
+                        (g.cfg == kDirectCfg || (g.Cin % 4 == 0 && g.seg0 % g.Cin == 0 && g.S1 * (g.seg0 / g.Cin) <= 31)); // one validity bit per tap (igemm.hip)
         GemmArgs k{};
         k.pro = g.pro, k.epi = g.epi;
         k.N = g.N, k.S1 = g.S1, k.seg0 = g.seg0, k.M = (i64)g.B * g.P1 * g.P0, k.L0 = g.L0, k.Cin = g.Cin;

@@ -148,17 +148,38 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     const i64 rowLen = (i64)p.L0 * p.Cin;
     const int rowLenI = (int)rowLen;
     const float *aRow[AR]; // X + b*xBS + in1_0*rowLen + e0  (tap s1 = 0, k = 0)
-    int aIn1[AR], aE0[AR];
     bool aRowOk[AR];
+    // General (conv) addressing: validity of a staged chunk depends only on (row, tap), tap c = k / Cin =
+    // s1 * (seg0 / Cin) + (tap along axis 0) - padding starts and ends at whole taps - so each row carries ONE
+    // bit per tap, computed here once per tile; the K walk then tests a bit instead of re-deriving four range
+    // checks per row and K-tile (measured: the address arithmetic of the general path cost the 3x3 rewrites 10 %).
+    unsigned aTapMask[AR];
     float aMean[AR], aScale[AR];
+    const int taps0 = p.seg0 / p.Cin;
 #pragma unroll
     for (int i = 0; i < AR; ++i)
     {
         const int4 ri = rowinfo[srow + i * RP];
         aRowOk[i] = ri.w >= 0;
-        aIn1[i] = ri.y * p.stride1 - p.pad1;
-        aE0[i] = (ri.z * p.stride0 - p.pad0) * p.Cin;
-        aRow[i] = p.X + (i64)ri.x * p.xBS + (i64)aIn1[i] * rowLen + aE0[i];
+        const int in1_0 = ri.y * p.stride1 - p.pad1;
+        const int e0 = (ri.z * p.stride0 - p.pad0) * p.Cin;
+        aRow[i] = p.X + (i64)ri.x * p.xBS + (i64)in1_0 * rowLen + e0;
+        aTapMask[i] = 0;
+        if (!LIN && aRowOk[i])
+        {
+            unsigned m0bits = 0; // taps along axis 0 whose chunk lies inside the row
+            for (int t0 = 0; t0 < taps0; ++t0)
+            {
+                const int e = e0 + t0 * p.Cin;
+                m0bits |= (e >= 0 && e < rowLenI ? 1u : 0u) << t0;
+            }
+            for (int s = 0; s < p.S1; ++s)
+            {
+                const int in1 = in1_0 + s * p.dil1;
+                if (in1 >= 0 && in1 < p.L1)
+                    aTapMask[i] |= m0bits << (s * taps0);
+            }
+        }
         aMean[i] = 0.f, aScale[i] = 1.f;
         if (PRO == PRO_AFFINE && aRowOk[i])
         {
@@ -201,6 +222,13 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
             offb -= p.seg0;
             ++s1;
         }
+    int tapC = 0, tapOff = slane * 4; // tap index kl / Cin and offset inside the tap
+    if (!LIN)
+        while (tapOff >= p.Cin)
+        {
+            tapOff -= p.Cin;
+            ++tapC;
+        }
     const float *addrA[AR], *addrB[BR], *addrG = p.zero;
     unsigned maskNext = 0, maskHeld = 0;
     i64 stepA[AR], stepB[BR]; // LIN: per-row advance (0 for rows that stay on the zero page)
@@ -208,26 +236,23 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
     // addresses of the next tile to fetch, in two halves (the interleaved loop slots them between MFMA groups):
     // addrs_A = validity + A row addresses, addrs_B = B row addresses + advance of the K walk
     int segOffCur = 0;
-    bool kpOkCur = true, kOkCur = true;
+    unsigned tapBit = 0;
     // general addressing of the A rows; half = 0 / 1: first / second half of the rows (the tile-wide
     // quantities are set up with the first half), 2: all rows
     auto addrs_A_general = [&](int half) {
         if (half != 1)
         {
             maskNext = 0;
-            kOkCur = kl < p.K;
-            kpOkCur = kl < p.Kp;
+            tapBit = tapC < 32 ? 1u << tapC : 0u; // taps beyond K (k >= K) have no bit in any row mask
             segOffCur = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
             if (PRO == PRO_GN_GELU)
-                addrG = p.proW + (kOkCur ? kl : 0);
+                addrG = p.proW + (kl < p.K ? kl : 0);
         }
 #pragma unroll
         for (int i = 0; i < AR; ++i)
             if (half == 2 || (i < (AR + 1) / 2) == (half == 0))
             {
-                const int in1 = aIn1[i] + s1 * p.dil1;
-                const int e = aE0[i] + offb;
-                const bool ok = kOkCur && aRowOk[i] && in1 >= 0 && in1 < p.L1 && e >= 0 && e < rowLenI;
+                const bool ok = (aTapMask[i] & tapBit) != 0u;
                 addrA[i] = ok ? aRow[i] + segOffCur : p.zero;
                 maskNext |= (ok ? 1u : 0u) << i;
             }
@@ -277,15 +302,37 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmA
                 addrB[i] += stepB[i];
             return;
         }
+        // B rows advance like a linear layer's. k >= Kp (second half of the last K-tile when Kp is an odd
+        // multiple of 16) reads the next weight row / the zeroed tail of the blob: those k meet A chunks of
+        // the zero page (no tap bit), and 0 x finite adds exactly 0.
+        if (!linInit)
+        {
+            linInit = true;
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
-            addrB[i] = (kpOkCur && bRowOk[i]) ? bRow[i] + kl : p.zero;
+            for (int i = 0; i < BR; ++i)
+            {
+                addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
+                stepB[i] = bRowOk[i] ? 16 * KS : 0;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                addrB[i] += stepB[i];
+        }
         kl += 16 * KS;
         offb += 16 * KS;
         if (p.S1 > 1 && offb >= p.seg0)
         {
             offb -= p.seg0;
             ++s1;
+        }
+        tapOff += 16 * KS;
+        while (tapOff >= p.Cin)
+        {
+            tapOff -= p.Cin;
+            ++tapC;
         }
     };
     auto compute_addrs = [&]() {

@@ -1,15 +1,14 @@
 #!/bin/bash
-# ablation of the attention tile loop (diagnostic variant libraries, results wrong by construction)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out; rm -f gpurun_out/abl.log
-for v in base anosm anostage anov anosmv apure; do
+for v in base noaddr; do
   lib=$R/demucs_cpp_amd/lib/libdemucs_hip_$v.so; [ $v = base ] && lib=$R/demucs_cpp_amd/lib/libdemucs_hip.so
-  ( DMX_LIB=$lib timeout 300 python tools/prof_ops.py abl_$v 2>&1 | grep -v amdgpu.ids | grep -E "^\[|attention" ) >> gpurun_out/abl.log
+  ( DMX_LIB=$lib timeout 300 python tools/prof_ops.py abl_$v 2>&1 | grep -v amdgpu.ids | grep -E "^\[|igemm" ) >> gpurun_out/abl.log
 done
 cat gpurun_out/abl.log
 python - <<'PY'
-ops=["crosstransformer.layers.0.attn","crosstransformer.layers.1.attn","crosstransformer.layers_t.0.attn","crosstransformer.layers_t.1.attn"]
-for v in ["base","anosm","anostage","anov","anosmv","apure"]:
+ops=["crosstransformer.layers.0.linear1","crosstransformer.layers.0.linear2","decoder.0.rewrite","decoder.1.rewrite","decoder.2.rewrite","decoder.3.rewrite","decoder.1.conv_tr","encoder.3.conv","encoder.2.conv","tdecoder.0.rewrite"]
+for v in ["base","noaddr"]:
     rows={l.split('\t')[0]:l.rstrip().split('\t') for l in open(f"gpurun_out/ops_abl_{v}.tsv")}
-    print(v.ljust(8)," ".join(f"{o.split('.')[1]+'.'+o.split('.')[2]}:{float(rows[o][2]):.3f}ms/{float(rows[o][3])/float(rows[o][2])/1e9:5.1f}TF" for o in ops if o in rows))
+    print(v.ljust(8)," ".join(f"{o.replace('crosstransformer.layers','ct')}:{float(rows[o][2]):.3f}/{float(rows[o][3])/float(rows[o][2])/1e9:5.1f}" for o in ops if o in rows))
 PY
