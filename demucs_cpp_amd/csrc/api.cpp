@@ -59,10 +59,10 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
         return fail(DMX_ERR_ARG, "dmx_model_load: device %d out of range (have %d)", device, ndev);
     m->device = device;
     HIPCHK(hipSetDevice(device));
-    // + 256 B: the igemm staging prefetches one K-tile beyond the last one (never used, must be readable)
-    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 256));
+    // + 1 KB: the igemm staging prefetches two K-tiles (2 x 128 B per row) beyond the last one (never used, must be readable)
+    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 1024));
     // the tail must read as finite numbers (it meets zero activations: 0 x NaN would poison an accumulator)
-    hipError_t e = hipMemset(reinterpret_cast<char *>(m->dW) + m->pm.blob.size() * sizeof(float), 0, 256);
+    hipError_t e = hipMemset(reinterpret_cast<char *>(m->dW) + m->pm.blob.size() * sizeof(float), 0, 1024);
     if (e == hipSuccess)
         e = hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess)
@@ -135,8 +135,9 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     if (!validate_plan(*p, why))
         return fail(DMX_ERR_ARG, "dmx_ctx_create: unsupported geometry (%s)", why.c_str());
     c->arenaFloats = p->arenaFloats;
-    HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float)));
-    HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float)));
+    // + 1 KB of slack behind the last activation for the same prefetch
+    HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float) + 1024));
+    HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float) + 1024));
     HIPCHK(hipMemcpy(c->dA, p->constants.data(), p->constants.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
