@@ -738,8 +738,9 @@ extern "C" int dmx_debug_n_ops(const dmx_ctx *c)
 // algorithmic work of one op: 2*MAC flops, and bytes with every operand read / result written once
 static void op_work(const Op &op, const char *&kernel, double &flops, double &bytes)
 {
-    static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48",
-                                     "igemm_256x16",  "igemm_128x32", "igemm_128x64", "igemm_64x128", "dgemm_direct"};
+    static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48", "igemm_256x16", "igemm_128x32",
+                                     "igemm_128x64",  "igemm_64x128", "dgemm_direct", "igemm_64x64", "igemm_64x96", "igemm_64x48",
+                                     "igemm_64x32",   "igemm_64x64",  "igemm_128x16"};
     flops = bytes = 0;
     kernel = "?";
     switch (op.kind)

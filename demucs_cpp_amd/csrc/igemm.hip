@@ -950,6 +950,29 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(5, 4, 1, 2, 2, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
         DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
         DMX_CASE(6, 4, 1, 2, 4, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        // half-height siblings (plan.cpp refine_cfg): cfg 9: 64x64 of 7; 10: 64x96 of 2; 11: 64x48 of 3; 12: 64x32 of 5;
+        // 13: 64x64 (4 x 1 waves) of 6; 14: 128x16 of 4
+        DMX_CASE(9, 2, 2, 2, 2, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(9, 2, 2, 2, 2, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(9, 2, 2, 2, 2, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(9, 2, 2, 2, 2, 2, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(9, 2, 2, 2, 2, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(10, 4, 1, 1, 6, DMX_CFG2_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(10, 4, 1, 1, 6, DMX_CFG2_KS, PRO_NONE, EPI_GLU)
+        DMX_CASE(10, 4, 1, 1, 6, DMX_CFG2_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(10, 4, 1, 1, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(10, 4, 1, 1, 6, DMX_CFG2_KS, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(11, 4, 1, 1, 3, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(11, 4, 1, 1, 3, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(11, 4, 1, 1, 3, DMX_SMALL_KS, PRO_AFFINE, EPI_LINEAR)
+        DMX_CASE(12, 4, 1, 1, 2, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
+        DMX_CASE(12, 4, 1, 1, 2, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(12, 4, 1, 1, 2, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(13, 4, 1, 1, 4, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
+        DMX_CASE(13, 4, 1, 1, 4, DMX_SMALL_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(13, 4, 1, 1, 4, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(14, 4, 1, 2, 1, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(14, 4, 1, 2, 1, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
     default:
         return -1;
     }

@@ -60,6 +60,46 @@ int choose_cfg(i64 M1, int N, bool paired)
     return tiles128 >= 256 ? 0 : 7;
 }
 
+int half_cfg(int cfg, bool stat)
+{
+    switch (cfg)
+    {
+    case 0:
+        return 7;
+    case 7:
+        return stat ? -1 : 9;
+    case 2:
+        return 10;
+    case 3:
+        return 11;
+    case 5:
+        return 12;
+    case 6:
+        return 13;
+    case 4:
+        return 14;
+    default:
+        return -1;
+    }
+}
+
+// Work per CU is what counts (co-resident workgroups share one matrix pipe per SIMD): a launch of T tiles
+// keeps the chip busy for ceil(T / 256) tile-rounds of its busiest CU, efficiency T / (256 ceil(T / 256)).
+// Large batches are efficient with the big tile; one segment (M = 2688 / 1344 rows) is not: 84 tiles of
+// 128x128 for a transformer linear2 leave two thirds of the CUs idle, 336 tiles of 64x64 do not.
+int refine_cfg(int cfg, i64 M, int N, bool stat)
+{
+    auto eff = [&](int c) {
+        const i64 T = ((M + kTileCfgs[c].BM - 1) / kTileCfgs[c].BM) * ((N + kTileCfgs[c].BN - 1) / kTileCfgs[c].BN);
+        return (double)T / (256.0 * (double)((T + 255) / 256));
+    };
+    int best = cfg;
+    for (int c = cfg; c >= 0 && eff(best) < 0.85; c = half_cfg(c, stat))
+        if (eff(c) > eff(best) + 1e-9)
+            best = c;
+    return best;
+}
+
 bool direct_available(int N, int S1, int seg0, int pro, int epi)
 {
     const int NF = (N + 15) / 16;
@@ -127,7 +167,7 @@ struct Builder
         g.Kp = rup(g.K, 16);
         g.Np = rup(g.N, 16);
         g.xBatchStride = (i64)g.L1 * g.L0 * g.Cin;
-        g.cfg = choose_cfg((i64)g.P1 * g.P0, g.N, paired);
+        g.cfg = refine_cfg(choose_cfg((i64)g.P1 * g.P0, g.N, paired), (i64)g.B * g.P1 * g.P0, g.N, g.rowstat >= 0);
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
         // (the direct kernels carry no residual operand for the LINEAR / TRCONV epilogues)
         const bool resOk = !((g.epi == EPI_LINEAR || g.epi == EPI_TRCONV) && g.res >= 0);

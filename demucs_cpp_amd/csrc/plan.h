@@ -235,9 +235,23 @@ static const TileCfg kTileCfgs[] = {
     {128, 64},  // 6
     {64, 128},  // 7  same column decomposition as 0 (2 waves x 4 fragments): bit-identical row statistics
     {16, 256},  // 8  kDirectCfg: dgemm.hip direct kernels, one wave owns 16 rows x all columns (NB = 1)
+    // half-height siblings for launches that would leave CUs idle (few segments in flight). Same column
+    // decomposition as the tile they replace (waves x fragments along N), so the row statistics - and every
+    // other output bit - are identical; 64x64 (2 waves x 2 fragments along N) only replaces ops without row statistics.
+    {64, 64},   // 9   of 7 (ops without row statistics only)
+    {64, 96},   // 10  of 2
+    {64, 48},   // 11  of 3
+    {64, 32},   // 12  of 5
+    {64, 64},   // 13  of 6 (4 x 1 waves)
+    {128, 16},  // 14  of 4
 };
-static const int kNumTileCfgs = 9;
+static const int kNumTileCfgs = 15;
 static const int kDirectCfg = 8;
+// cfg -> its half-height sibling (-1: none); stat = the op writes row statistics
+int half_cfg(int cfg, bool stat);
+// tile for an op at the ACTUAL number of rows M (all segments in flight): the largest tile of the chain
+// cfg -> half_cfg(cfg) -> ... that keeps the 256 CUs evenly busy
+int refine_cfg(int cfg, i64 M, int N, bool stat);
 // shapes served by the direct kernels (must match the table in dgemm.hip)
 bool direct_available(int N, int S1, int seg0, int pro, int epi);
 // M1 = rows per batch element: the choice never depends on the batch size, so results are
