@@ -150,6 +150,8 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
         c->streamMode = e ? atoi(e) : 0;
         const char *g = getenv("DMX_GRAPH");
         c->graphMode = g ? atoi(g) : 1;
+        const char *f = getenv("DMX_FUSE_ISTFT");
+        c->fuseIstft = f ? atoi(f) : 1;
     }
     HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
     HIPCHK(hipMalloc((void **)&c->dStats, sizeof(float) * 4));
@@ -340,13 +342,19 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_ISTFT:
     {
         const Istft &t = op.istft;
-        launch_istft(IstftArgs{a(t.x), a(t.stats), a(t.frames), t.B, t.T, t.S, a(t.window), a(t.twiddle)}, s);
+        if (!(t.fused && c->fuseIstft)) // fused: runs inside the following OP_OLA
+            launch_istft(IstftArgs{a(t.x), a(t.stats), a(t.frames), t.B, t.T, t.S, a(t.window), a(t.twiddle)}, s);
         break;
     }
     case OP_OLA:
     {
         const Ola &o = op.ola;
-        launch_ola(OlaArgs{a(o.frames), a(o.xt), a(o.statsT), a(o.wss), a(o.out), o.B, o.T, o.S, o.seg, o.pad}, s);
+        if (o.x >= 0 && c->fuseIstft)
+            launch_istft_ola(IstftOlaArgs{a(o.x), a(o.stats), a(o.xt), a(o.statsT), a(o.wss), a(o.window), a(o.twiddle), a(o.out), o.B, o.T,
+                                          o.S, o.seg, o.pad, 0, 0},
+                             s);
+        else
+            launch_ola(OlaArgs{a(o.frames), a(o.xt), a(o.statsT), a(o.wss), a(o.out), o.B, o.T, o.S, o.seg, o.pad}, s);
         break;
     }
     default:

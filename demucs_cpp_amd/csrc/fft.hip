@@ -245,4 +245,166 @@ void launch_ola(const OlaArgs &a, hipStream_t s)
     hipLaunchKernelGGL(ola_kernel, dim3(gx, a.B * a.S * 2), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ISTFT + overlap-add + crop + time-branch sum in ONE kernel: the inverse frames never reach HBM (the
+// two-kernel form above writes and re-reads [B][S][2][T][4096] floats = 1.06 GB per 24-segment step).
+//
+// A workgroup owns (batch b, source src, chunk of `fpc` consecutive frames) and walks its frames in order.
+// After the inverse FFT thread `tid` holds the samples i = tid + 256 j (j < 16) of the frame; sample i of
+// frame f lands on position n = 1024 f + i of the padded signal, i.e. in hop H = f + (j >> 2) at offset
+// tid + 256 (j & 3): always one of THIS thread's 16 accumulators, ring slot H & 3. A hop receives its last
+// contribution from frame H itself, so after frame f has been added slot f & 3 is complete: it is written
+// out (window-sum-square division done per term, crop, + de-normalised time branch: exactly the arithmetic
+// and the summation order of istft_kernel + ola_kernel, bit for bit) and cleared. The ring rotates with f, so
+// the step is instantiated for the 4 values of f & 3 (register indices must be compile-time constants).
+// Chunks start 3 frames early (recomputed halo, no output) so that every hop they emit has all 4 addends.
+//
+// The four (six) sources of one (b, chunk) read the same 64-byte lines of x (16 B each): they are dealt to the
+// SAME XCD, adjacent in dispatch order, so the lines come from HBM once and from that XCD's L2 afterwards.
+template <int PH>
+__device__ __forceinline__ void istft_ola_step(const IstftOlaArgs &p, float2 (&acc)[4][4], const float2 *bufA, int f, int tid, bool add,
+                                               bool emit, int b, int src, float meanT, float stdT)
+{
+    if (add)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+            const int i = tid + 256 * j;
+            const float2 z = bufA[i];
+            const float w = p.window[i];
+            const float den = p.wss[f * 1024 + i] + 1e-8f;
+            const float y0 = z.x * w, y1 = z.y * w; // the value istft_kernel stores in `frames`
+            float2 &a = acc[(PH + (j >> 2)) & 3][j & 3];
+            a.x += y0 * 1.0f / 4096.0f / den;
+            a.y += y1 * 1.0f / 4096.0f / den;
+        }
+    }
+    if (emit)
+    {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+        {
+            const int n = f * 1024 + tid + 256 * jj;
+            const int i = n - (2048 + p.pad);
+            if (i >= 0 && i < p.seg)
+            {
+                const float2 tb = *reinterpret_cast<const float2 *>(p.xt + ((i64)b * p.seg + i) * (2 * p.S) + src * 2);
+                p.out[(((i64)b * p.S + src) * 2 + 0) * p.seg + i] = acc[PH][jj].x + (stdT * tb.x + meanT);
+                p.out[(((i64)b * p.S + src) * 2 + 1) * p.seg + i] = acc[PH][jj].y + (stdT * tb.y + meanT);
+            }
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+        acc[PH][jj] = make_float2(0.f, 0.f); // slot f & 3 now collects hop f + 4
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
+{
+    __shared__ float2 bufA[FFT_N];
+    __shared__ float2 bufB[FFT_N];
+    __shared__ float2 twS[2048]; // twiddles in LDS: a chunk of ~30 frames amortises the 16 KB; the one-frame-per-workgroup
+                                 // kernels above take them from L1/L2 (3 loads per butterfly and stage in the dependency chain)
+    const int tid = threadIdx.x;
+    // workgroup -> (group = (b, chunk), source): all sources of a group on one XCD (block id % 8)
+    const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
+    const int src = (int)(jq % (unsigned)p.S);
+    const unsigned group = (jq / (unsigned)p.S) * 8u + xcd;
+    if (group >= (unsigned)(p.B * p.nch))
+        return;
+    const int b = (int)(group / (unsigned)p.nch), ch = (int)(group - (unsigned)b * (unsigned)p.nch);
+    for (int k = tid; k < 2048; k += 256)
+        twS[k] = reinterpret_cast<const float2 *>(p.twiddle)[k];
+    const int CS = 4 * p.S;
+    const float mean = p.stats[b * 4], stdv = p.stats[b * 4 + 2];
+    const float meanT = p.statsT[b * 4], stdT = p.statsT[b * 4 + 2];
+    // model frames t in [t0, t1) are this chunk's; padded-signal frame index f = t + 2 (frames 0, 1, T+2, T+3
+    // of the reference are zero, model_inference.cpp:439-444). The last chunk also emits the 3 hops behind
+    // the last frame (their addends all exist by then).
+    const int t0 = ch * p.fpc, t1 = min(p.T, t0 + p.fpc);
+    const int fEnd = (ch == p.nch - 1) ? p.T + 2 + 3 : t1 + 2;
+    float2 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            acc[a][c] = make_float2(0.f, 0.f);
+    // the spectrum of the NEXT frame travels global -> registers while the current frame is transformed
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 xr[8];
+    auto fetch = [&](int f) {
+        const int t = min(f - 2, p.T - 1); // beyond the last frame: a harmless re-read
+        const float *xin = p.x + (((i64)b * p.T + t) * 2048) * CS + src * 4;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            xr[m] = *reinterpret_cast<const f32x4 *>(xin + (i64)(tid + 256 * m) * CS);
+    };
+    const int fBeg = max(2, t0 + 2 - 3);
+    fetch(fBeg);
+    __syncthreads(); // twS
+    for (int f = fBeg; f < fEnd; ++f)
+    {
+        const int t = f - 2;
+        const bool add = t < p.T;
+        if (add)
+        {
+            // Z[k] = X0[k] + i X1[k] with Hermitian extension; X*sqrt(N) (dsp.cpp:160-165);
+            // DC imaginary parts ignored, Nyquist bin = 0 (model_inference.cpp:439-442)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+            {
+                const int k = tid + 256 * m;
+                const f32x4 v = xr[m];
+                float re0 = (stdv * v[0] + mean) * 64.0f, im0 = (stdv * v[1] + mean) * 64.0f;
+                float re1 = (stdv * v[2] + mean) * 64.0f, im1 = (stdv * v[3] + mean) * 64.0f;
+                if (k == 0)
+                {
+                    im0 = 0.f;
+                    im1 = 0.f;
+                }
+                bufA[k] = make_float2(re0 - im1, im0 + re1);
+                if (k > 0)
+                    bufA[FFT_N - k] = make_float2(re0 + im1, re1 - im0);
+            }
+            if (tid == 0)
+                bufA[2048] = make_float2(0.f, 0.f);
+            fetch(f + 1);
+            __syncthreads();
+            fft4096<+1>(bufA, bufB, twS, tid); // ends with a barrier: bufA holds the frame
+        }
+        const bool emit = t >= t0; // halo frames only build up the ring
+        switch (f & 3)
+        {
+        case 0:
+            istft_ola_step<0>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            break;
+        case 1:
+            istft_ola_step<1>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            break;
+        case 2:
+            istft_ola_step<2>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            break;
+        default:
+            istft_ola_step<3>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            break;
+        }
+        __syncthreads(); // bufA is rewritten by the next frame
+    }
+}
+
+void launch_istft_ola(const IstftOlaArgs &a0, hipStream_t s)
+{
+    IstftOlaArgs a = a0;
+    // enough workgroups for ~4 per CU; every chunk recomputes a 3-frame halo, so no shorter than 8 frames
+    const int want = (1024 + a.B * a.S - 1) / (a.B * a.S);
+    a.nch = want < 1 ? 1 : want;
+    if (a.nch > a.T / 8)
+        a.nch = a.T / 8 > 0 ? a.T / 8 : 1;
+    a.fpc = (a.T + a.nch - 1) / a.nch;
+    a.nch = (a.T + a.fpc - 1) / a.fpc;
+    const unsigned groups = (unsigned)(a.B * a.nch);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(8u * ((groups + 7u) / 8u) * (unsigned)a.S), dim3(256), 0, s, a);
+}
+
 } // namespace dmx

@@ -143,6 +143,15 @@ struct OlaArgs
     int B, T, S, seg, pad;
 };
 void launch_ola(const OlaArgs &a, hipStream_t s);
+// ISTFT + overlap-add + time-branch sum in one kernel (the inverse frames stay in registers)
+struct IstftOlaArgs
+{
+    const float *x, *stats, *xt, *statsT, *wss, *window, *twiddle;
+    float *out;
+    int B, T, S, seg, pad;
+    int nch, fpc; // frame chunks per (batch, source) and frames per chunk (filled by the launcher)
+};
+void launch_istft_ola(const IstftOlaArgs &a, hipStream_t s);
 
 // ---- track level (model_apply.cpp:60-288) ----
 // partial (sum, sumsq) of the mono reference (mean over channels); audio interleaved [n][2]

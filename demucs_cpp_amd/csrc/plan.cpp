@@ -718,13 +718,13 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
         op.kind = OP_ISTFT;
         op.stream = 0;
         op.name = "istft";
-        op.istft = Istft{aDin[4], aStF, aFrames, B, T, S, cWindow, cTwiddle};
+        op.istft = Istft{aDin[4], aStF, aFrames, B, T, S, cWindow, cTwiddle, 1};
         pl.ops.push_back(op);
         Op o2;
         o2.kind = OP_OLA;
         o2.stream = 0;
         o2.name = "ola";
-        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad};
+        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle};
         pl.ops.push_back(o2);
     }
     compute_deps(pl);
@@ -822,6 +822,11 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
         Wr(op.istft.frames, (i64)op.istft.B * op.istft.S * 2 * op.istft.T * 4096);
         break;
     case OP_OLA:
+        if (op.ola.x >= 0) // fused execution reads the ISTFT's operands itself
+        {
+            R(op.ola.x, (i64)op.ola.B * op.ola.T * 2048 * 4 * op.ola.S);
+            R(op.ola.stats, (i64)op.ola.B * 4);
+        }
         R(op.ola.frames, (i64)op.ola.B * op.ola.S * 2 * op.ola.T * 4096);
         R(op.ola.xt, (i64)op.ola.B * op.ola.seg * 2 * op.ola.S);
         R(op.ola.statsT, (i64)op.ola.B * 4);

@@ -164,6 +164,8 @@ struct Istft
     i64 frames; // A: [B][S][2][T][4096] windowed inverse frames (y * hann)
     int B, T, S;
     i64 window, twiddle;
+    int fused; // 1: the GPU runs this op inside the following OP_OLA (fft.hip istft_ola_kernel: the frames never
+               // reach HBM); the CPU interpreter keeps the two-step form, which defines the arithmetic
 };
 
 struct Ola
@@ -174,6 +176,7 @@ struct Ola
     i64 wss;     // A constant: [(T+4-1)*1024 + 4096] window sum-square of T+4 frames
     i64 out;     // A: [B][S][2][seg] planar
     int B, T, S, seg, pad;
+    i64 x, stats, window, twiddle; // operands of the preceding OP_ISTFT (fused execution), -1 otherwise
 };
 
 struct Tap
