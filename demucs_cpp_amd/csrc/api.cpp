@@ -797,12 +797,20 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
         break;
     case OP_ISTFT:
         kernel = "istft";
+        if (op.istft.fused)
+            break; // accounted with the fused kernel (OP_OLA)
         flops = (double)op.istft.B * op.istft.T * op.istft.S * 5.0 * 4096 * 12;
         bytes = 4.0 * op.istft.B * op.istft.T * op.istft.S * (2048.0 * 4 + 2 * 4096.0);
         break;
     case OP_OLA:
         kernel = "ola";
         bytes = 4.0 * op.ola.B * op.ola.S * 2 * ((double)op.ola.T * 4096 + 2.0 * op.ola.seg);
+        if (op.ola.x >= 0) // fused execution (the default): spectrum in, time branch in, stems out; the ISTFT's flops
+        {
+            kernel = "istft_ola";
+            flops = (double)op.ola.B * op.ola.T * op.ola.S * 5.0 * 4096 * 12;
+            bytes = 4.0 * op.ola.B * ((double)op.ola.T * 2048 * 4 * op.ola.S + 4.0 * op.ola.seg * op.ola.S);
+        }
         break;
     default:
         break;

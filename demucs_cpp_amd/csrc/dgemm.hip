@@ -401,6 +401,24 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
             cur = nxt;
         }
     }
+    else if constexpr (PIPE == 3)
+    {
+        // two fragments in flight per wave: these kernels are bound by the bytes a CU keeps in flight (HBM latency
+        // under load ~3 us x 6 TB/s = 74 KB per CU), not by issue - a third stage costs registers (fewer waves) but
+        // each wave then covers twice the latency
+        Stage s0, s1, s2;
+        fetch(gwave, s0);
+        fetch(gwave + nwaves, s1);
+        for (int frag = gwave; frag < nfrag; frag += 3 * nwaves)
+        {
+            fetch(frag + 2 * nwaves, s2);
+            compute(s0);
+            fetch(frag + 3 * nwaves, s0);
+            compute(s1);
+            fetch(frag + 4 * nwaves, s1);
+            compute(s2);
+        }
+    }
     else
     {
         Stage sa, sb;
