@@ -1,0 +1,75 @@
+"""tools/eval_sdr.py (counterpart of /root/reference/scripts/evaluate-demixed-output.py): the windowed
+BSS-Eval-v4 image SDR on signals with a known answer, and the opt-in real-weights check against
+/root/reference/.github/SDR_scores.md (needs a checkpoint + a MUSDB18-HQ track: skipped without them)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import eval_sdr  # noqa: E402
+
+
+def test_known_sdr_values():
+    rng = np.random.default_rng(0)
+    n = 5 * 44100 + 1234
+    ref = rng.standard_normal((n, 2))
+    noise = rng.standard_normal((n, 2))
+    for target_db in (0.0, 10.0, 37.5):
+        g = 10 ** (-target_db / 20)
+        f = eval_sdr.sdr_framewise(ref, ref + g * noise)
+        assert len(f) == 5 and np.all(np.abs(f - target_db) < 0.1)  # ||noise|| ~ ||ref|| per window
+    assert np.all(np.isinf(eval_sdr.sdr_framewise(ref, ref)))
+    # gain error: est = a ref -> SDR = -20 log10 |1 - a|
+    assert np.allclose(eval_sdr.sdr_framewise(ref, 0.9 * ref), 20.0, atol=1e-9)
+    # silent reference / estimate windows are NaN and do not enter the median
+    ref2 = ref.copy(); ref2[:44100] = 0
+    est2 = ref2 + 0.1 * noise; est2[44100:2 * 44100] = 0
+    f = eval_sdr.sdr_framewise(ref2, est2)
+    assert np.isnan(f[0]) and np.isnan(f[1]) and np.all(np.isfinite(f[2:]))
+    med = eval_sdr.track_sdr({"vocals": ref2}, {"vocals": est2})["vocals"]
+    assert abs(med - 20.0) < 0.1
+
+
+def test_cli_reads_driver_stems(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from wavio import write_wav_f32
+    rng = np.random.default_rng(1)
+    n = 3 * 44100
+    rd, ed = tmp_path / "ref", tmp_path / "est"
+    rd.mkdir(); ed.mkdir()
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        r = rng.standard_normal((2, n)).astype(np.float32) * 0.1
+        write_wav_f32(str(rd / f"{name}.wav"), r)
+        write_wav_f32(str(ed / f"target_{i}_{name}.wav"), (r + 0.01 * rng.standard_normal((2, n))).astype(np.float32))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_sdr.py"), str(rd), str(ed)], capture_output=True, text=True)
+    assert out.returncode == 0
+    lines = [ln for ln in out.stdout.splitlines() if "SDR" in ln]
+    assert len(lines) == 4 and all(abs(float(ln.split("SDR:")[1]) - 20.0) < 0.2 for ln in lines)
+
+
+@pytest.mark.gpu
+def test_real_weights_sdr_matches_reference_scores(tmp_path):
+    """Opt-in: DMX_REAL_WEIGHTS = a htdemucs PyTorch checkpoint (.th) or a converted ggml-model-htdemucs-4s-f16.bin,
+    DMX_MUSDB_TRACK = directory with mixture.wav + {drums,bass,other,vocals}.wav of 'Zeno - Signs' (MUSDB18-HQ test).
+    Runs the CLI with the shift offset of SDR_scores.md (1337) and requires every target within +-0.1 dB of the
+    reference's own C++ numbers (/root/reference/.github/SDR_scores.md:16-20). Until this has run somewhere, parity of
+    conv / GEMM / attention with the Eigen reference stays "partial" (DESIGN.md section 3)."""
+    weights, track = os.environ.get("DMX_REAL_WEIGHTS"), os.environ.get("DMX_MUSDB_TRACK")
+    if not weights or not track:
+        pytest.skip("DMX_REAL_WEIGHTS / DMX_MUSDB_TRACK not set (no checkpoints or MUSDB18-HQ in this environment)")
+    model = weights
+    if weights.endswith(".th"):
+        model = str(tmp_path / "ggml-model-htdemucs-4s-f16.bin")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convert_pth_to_dmc.py"), weights, model])
+    exe = os.path.join(ROOT, "cli", "demucs.cpp.main")
+    out_dir = tmp_path / "stems"
+    env = dict(os.environ, DMX_SHIFT_OFFSET="1337")
+    subprocess.check_call([exe, model, os.path.join(track, "mixture.wav"), str(out_dir)], env=env)
+    refs, ests = eval_sdr.load_dirs(track, str(out_dir))
+    got = eval_sdr.track_sdr(refs, ests)
+    for name, want in eval_sdr.SDR_SCORES_MD_CPP_4S.items():
+        assert abs(got[name] - want) <= 0.1, (name, got[name], want)
