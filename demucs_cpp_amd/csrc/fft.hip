@@ -8,9 +8,11 @@
 //
 // Both stereo channels of a frame share ONE 4096-point complex FFT (z = x_L + i x_R;
 // the two half spectra are separated with the conjugate-symmetry identity), done as a
-// 12-stage radix-2 Stockham autosort FFT in LDS by one 256-thread workgroup per frame.
-// The whole STFT/ISTFT is < 1% of the segment's HBM bytes; the design goal here is
-// coalesced float2/float4 global access, not FFT throughput.
+// 6-stage radix-4 Stockham autosort FFT in LDS by a 256-thread workgroup. The forward transform
+// runs one workgroup per frame; the inverse runs fused with the overlap-add, crop and time-branch
+// sum (istft_ola_kernel: one workgroup per (batch, source, chunk of frames), the inverse frames stay
+// in registers). istft_kernel + ola_kernel are the two-kernel form of the same arithmetic: the
+// executable specification (CPU interpreter) and the DMX_FUSE_ISTFT=0 path.
 #include "kernels.h"
 
 namespace dmx

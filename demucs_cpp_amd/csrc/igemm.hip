@@ -35,6 +35,12 @@
 #ifndef DMX_CFG2_KS
 #define DMX_CFG2_KS 2
 #endif
+#ifndef DMX_BIG_KS
+#define DMX_BIG_KS 2 // experiment: 1 = 16-deep K-tiles for the 128x128 / 64x128 tiles (half the LDS: 3 workgroups per CU)
+#endif
+#ifndef DMX_KS1_WAVES
+#define DMX_KS1_WAVES 1 // experiment: min waves per SIMD the KS == 1 kernels are compiled for
+#endif
 
 // Ablation switches for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_ABL_..."`): they remove one
 // ingredient of the interleaved K loop / the epilogue so that its cost can be read off a per-op profile.
@@ -81,7 +87,7 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
 // small pieces BETWEEN the eight 16-MFMA groups of tile t (pinned with sched_barrier), so a wave's
 // instruction stream is a uniform MFMA-dominated mix with no long matrix-idle stretch.
 template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN, bool IL>
-__global__ __launch_bounds__(256, KS == 2 ? 2 : 1) void igemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
 {
     static_assert(!IL || KS == 2, "interleaved loop is written for 2 k-chunks per tile");
     constexpr int BM = WAVES_M * WMF * 16;
@@ -919,18 +925,18 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
     switch (cfg * 100 + a.pro * 10 + a.epi)
     {
         // cfg 0: 128x128, cfg 7: 64x128 (same column decomposition)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_SCALE_RES)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_GLU)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_CASE(0, 2, 2, 4, 4, 2, PRO_GN_GELU, EPI_STATS_ONLY)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_NONE, EPI_LINEAR)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_NONE, EPI_SCALE_RES)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_NONE, EPI_GLU)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_NONE, EPI_TRCONV)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
-        DMX_CASE(7, 2, 2, 2, 4, 2, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_ONLY)
         // cfg 2: 128x96
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_GLU)

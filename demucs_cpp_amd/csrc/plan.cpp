@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -94,7 +95,10 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
         return (double)T / (256.0 * (double)((T + 255) / 256));
     };
     int best = cfg;
-    for (int c = cfg; c >= 0 && eff(best) < 0.85; c = half_cfg(c, stat))
+    if (const char *e = getenv("DMX_FORCE_HALF")) // experiment: 1 = one halving step for every op, 2 = two
+        for (int k = atoi(e); k > 0 && half_cfg(best, stat) >= 0; --k)
+            best = half_cfg(best, stat);
+    for (int c = best; c >= 0 && eff(best) < 0.85; c = half_cfg(c, stat))
         if (eff(c) > eff(best) + 1e-9)
             best = c;
     return best;

@@ -78,7 +78,7 @@ struct demucs_model
     bool is_4sources = true;
     std::vector<int> devices;  // HIP devices (env DMX_DEVICES="0,1,..."; "all"; default: device DMX_DEVICE or 0)
     int shift_offset = -1;     // -1: rand() % 22050 like src/model_apply.cpp:114; else fixed
-    int max_batch = 12;        // segments in flight per device (7.8 GB of arena; 3.4 ms per segment vs 4.1 at 4)
+    int max_batch = 12;        // segments in flight per device (7.8 GB of arena; 3.33 ms per segment, 3.9 at 4, 3.22 at 24: DMX_BATCH)
     dmx_engine *engine = nullptr;
     mutable std::mutex lock;
     demucs_model() {}
