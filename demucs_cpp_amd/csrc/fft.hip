@@ -8,7 +8,7 @@
 //
 // Both stereo channels of a frame share ONE 4096-point complex FFT (z = x_L + i x_R;
 // the two half spectra are separated with the conjugate-symmetry identity), done as a
-// 6-stage radix-4 Stockham autosort FFT in LDS by a 256-thread workgroup. The forward transform
+// 3-stage radix-16 Stockham autosort FFT in LDS by a 256-thread workgroup (one 16-point DFT per thread and stage). The forward transform
 // runs one workgroup per frame; the inverse runs fused with the overlap-add, crop and time-branch
 // sum (istft_ola_kernel: one workgroup per (batch, source, chunk of frames), the inverse frames stay
 // in registers). istft_kernel + ola_kernel are the two-kernel form of the same arithmetic: the
@@ -21,12 +21,8 @@ namespace dmx
 #define FFT_N 4096
 #define FFT_LOG 12
 
-// In-LDS Stockham radix-4 DIF FFT of FFT_N = 4^6 complex points (6 autosort stages, one barrier each;
-// the radix-2 version needed 12). After the call the result is in `a` (6 stages = even).
-// sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse. tw[k] = exp(-2 pi i k / 4096), k < 2048;
-// exponents in [2048, 3072) use w^(k) = -w^(k - 2048).
-// Stage with stride s (= 4^st), sub-transform length n = N/s, quarter m = n/4, p < m, q < s:
-//   y[q + s (4p + k)] = w_n^(p k) * sum_j omega_4^(j k) x[q + s (p + j m)],  omega_4 = -i (forward) / +i (inverse)
+// twiddle w_N^idx of the requested direction: tw[k] = exp(-2 pi i k / 4096), k < 2048; exponents in
+// [2048, 4096) use w^(k) = -w^(k - 2048)
 template <int SIGN>
 __device__ __forceinline__ float2 fft_tw(const float2 *__restrict__ tw, int idx)
 {
@@ -39,37 +35,82 @@ __device__ __forceinline__ float2 fft_tw(const float2 *__restrict__ tw, int idx)
 }
 __device__ __forceinline__ float2 cmul(const float2 a, const float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 
+// LDS position of element i: a XOR swizzle of the low 4 bits with the next 4. Every access pattern of the three
+// radix-16 stages below (reads x[j + 256 k] / 16-element blocks, writes y[16 p + k] / y[q + 256 p + 16 k] /
+// y[j + 256 k]) then puts the 16 lanes of a ds_read/write_b64 group on 16 distinct bank pairs.
+#define FSW(i) ((i) ^ (((i) >> 4) & 15))
+
+// in place 4-point DFT X_d = sum_e w4^(e d) x_e, w4 = -i (forward) / +i (inverse)
+template <int SIGN>
+__device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
+{
+    const float2 s02 = make_float2(x0.x + x2.x, x0.y + x2.y), d02 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 s13 = make_float2(x1.x + x3.x, x1.y + x3.y), d13 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    const float2 j13 = SIGN < 0 ? make_float2(d13.y, -d13.x) : make_float2(-d13.y, d13.x); // w4 * d13
+    x0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+    x1 = make_float2(d02.x + j13.x, d02.y + j13.y);
+    x2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+    x3 = make_float2(d02.x - j13.x, d02.y - j13.y);
+}
+template <int SIGN>
+__device__ __forceinline__ float2 mulw16(const float2 v, const float c, const float sn) // v * (c + i SIGN sn)
+{
+    const float si = SIGN < 0 ? -sn : sn;
+    return make_float2(v.x * c - v.y * si, v.x * si + v.y * c);
+}
+
+// In-LDS Stockham radix-16 FFT of FFT_N = 16^3 complex points: 3 autosort stages (one barrier each), every
+// thread does ONE 16-point DFT per stage in registers (4 x 4 decomposition, constants w16^(c d)). Half the LDS
+// traffic and half the barriers of the 6-stage radix-4 form it replaces. Input: a[FSW(i)]; result: b[FSW(i)].
+// sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse. tw[k] = exp(-2 pi i k / 4096), k < 2048.
+// Stage with stride s (= 16^st), sub-transform length n = N/s, m = n/16, p < m, q < s:
+//   y[q + s (16 p + k)] = w_n^(p k) * sum_j w16^(j k) x[q + s (p + j m)]
 template <int SIGN>
 __device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__restrict__ tw, int tid)
 {
     float2 *x = a, *y = b;
 #pragma unroll 1
-    for (int st = 0; st < FFT_LOG; st += 2)
+    for (int st = 0; st < FFT_LOG; st += 4)
     {
-        const int s = 1 << st;        // stride
-        const int m = FFT_N >> (st + 2); // quarter length of the sub-transform
+        const int s = 1 << st, m = 256 >> st;
+        const int p = tid >> st, q = tid & (s - 1);
+        float2 v[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 16; ++k)
         {
-            const int j = tid + i * 256; // butterfly index 0..1023
-            const int p = j >> st, q = j & (s - 1);
-            const float2 a0 = x[q + s * p];
-            const float2 a1 = x[q + s * (p + m)];
-            const float2 a2 = x[q + s * (p + 2 * m)];
-            const float2 a3 = x[q + s * (p + 3 * m)];
-            const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-            const float2 b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-            const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-            // (a1 - a3) * (-i) forward, * (+i) inverse
-            const float2 d = make_float2(a1.x - a3.x, a1.y - a3.y);
-            const float2 b3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-            const int e = p << st; // twiddle exponent of w_N for k = 1
-            const int o = q + s * (4 * p);
-            y[o] = make_float2(b0.x + b2.x, b0.y + b2.y);
-            y[o + s] = cmul(make_float2(b1.x + b3.x, b1.y + b3.y), fft_tw<SIGN>(tw, e));
-            y[o + 2 * s] = cmul(make_float2(b0.x - b2.x, b0.y - b2.y), fft_tw<SIGN>(tw, 2 * e));
-            y[o + 3 * s] = cmul(make_float2(b1.x - b3.x, b1.y - b3.y), fft_tw<SIGN>(tw, 3 * e));
+            const int i = q + s * (p + k * m);
+            v[k] = x[FSW(i)];
         }
+        // 16-point DFT: b_{c,d} = DFT4 over e of v[c + 4e] (in place -> v[c + 4d]); times w16^(c d); Y_{d + 4f} =
+        // DFT4 over c (in place -> v[f + 4d])
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            dft4<SIGN>(v[c], v[c + 4], v[c + 8], v[c + 12]);
+        v[1 + 4] = mulw16<SIGN>(v[1 + 4], 0.92387953251128674f, 0.38268343236508977f);   // w16^1
+        v[2 + 4] = mulw16<SIGN>(v[2 + 4], 0.70710678118654752f, 0.70710678118654752f);   // w16^2
+        v[3 + 4] = mulw16<SIGN>(v[3 + 4], 0.38268343236508977f, 0.92387953251128674f);   // w16^3
+        v[1 + 8] = mulw16<SIGN>(v[1 + 8], 0.70710678118654752f, 0.70710678118654752f);   // w16^2
+        v[2 + 8] = mulw16<SIGN>(v[2 + 8], 0.0f, 1.0f);                                   // w16^4
+        v[3 + 8] = mulw16<SIGN>(v[3 + 8], -0.70710678118654752f, 0.70710678118654752f);  // w16^6
+        v[1 + 12] = mulw16<SIGN>(v[1 + 12], 0.38268343236508977f, 0.92387953251128674f); // w16^3
+        v[2 + 12] = mulw16<SIGN>(v[2 + 12], -0.70710678118654752f, 0.70710678118654752f); // w16^6
+        v[3 + 12] = mulw16<SIGN>(v[3 + 12], -0.92387953251128674f, -0.38268343236508977f); // w16^9
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            dft4<SIGN>(v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3]);
+        const int o = q + s * 16 * p;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+            {
+                const int k = d + 4 * f;
+                float2 r = v[f + 4 * d];
+                if (st < 8 && k > 0) // the last stage has p = 0
+                    r = cmul(r, fft_tw<SIGN>(tw, (p * k) << st));
+                const int i = o + s * k;
+                y[FSW(i)] = r;
+            }
         __syncthreads();
         float2 *t = x;
         x = y;
@@ -109,7 +150,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
             j = 2 * (i64)p.seg - 1 - j;
         const float2 v = mix[j];
         const float w = p.window[i];
-        bufA[i] = make_float2(v.x * w, v.y * w);
+        bufA[FSW(i)] = make_float2(v.x * w, v.y * w);
     }
     // raw-mix statistics of this hop (time-branch z-norm, model_inference.cpp:138-141)
     double sT = 0.0, qT = 0.0;
@@ -132,8 +173,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
     const float sc = 1.0f / 64.0f;
     for (int k = tid; k < 2048; k += 256)
     {
-        const float2 zk = bufA[k];
-        const float2 zn = bufA[(FFT_N - k) & (FFT_N - 1)];
+        const float2 zk = bufB[FSW(k)]; // 3 stages: the result is in the second buffer
+        const float2 zn = bufB[FSW((FFT_N - k) & (FFT_N - 1))];
         // X0 = (Z[k] + conj(Z[N-k]))/2 ; X1 = -i (Z[k] - conj(Z[N-k]))/2
         const float re0 = 0.5f * (zk.x + zn.x) * sc, im0 = 0.5f * (zk.y - zn.y) * sc;
         const float re1 = 0.5f * (zk.y + zn.y) * sc, im1 = -0.5f * (zk.x - zn.x) * sc;
@@ -186,19 +227,19 @@ __global__ __launch_bounds__(256) void istft_kernel(const IstftArgs p)
             im1 = 0.f;
         }
         // X0 + i X1 = (re0 - im1) + i (im0 + re1)
-        bufA[k] = make_float2(re0 - im1, im0 + re1);
+        bufA[FSW(k)] = make_float2(re0 - im1, im0 + re1);
         if (k > 0) // conj(X0) + i conj(X1) = (re0 + im1) + i (re1 - im0)
-            bufA[FFT_N - k] = make_float2(re0 + im1, re1 - im0);
+            bufA[FSW(FFT_N - k)] = make_float2(re0 + im1, re1 - im0);
     }
     if (tid == 0)
-        bufA[2048] = make_float2(0.f, 0.f);
+        bufA[FSW(2048)] = make_float2(0.f, 0.f);
     __syncthreads();
     fft4096<+1>(bufA, bufB, tw, tid);
     float *f0 = p.frames + ((((i64)b * p.S + src) * 2 + 0) * p.T + t) * 4096;
     float *f1 = p.frames + ((((i64)b * p.S + src) * 2 + 1) * p.T + t) * 4096;
     for (int i = tid; i < FFT_N; i += 256)
     {
-        const float2 z = bufA[i];
+        const float2 z = bufB[FSW(i)];
         const float w = p.window[i];
         f0[i] = z.x * w;
         f1[i] = z.y * w;
@@ -273,7 +314,7 @@ __device__ __forceinline__ void istft_ola_step(const IstftOlaArgs &p, float2 (&a
         for (int j = 0; j < 16; ++j)
         {
             const int i = tid + 256 * j;
-            const float2 z = bufA[i];
+            const float2 z = bufA[FSW(i)]; // `bufA` here is the buffer that holds the transformed frame
             const float w = p.window[i];
             const float den = p.wss[f * 1024 + i] + 1e-8f;
             const float y0 = z.x * w, y1 = z.y * w; // the value istft_kernel stores in `frames`
@@ -365,33 +406,33 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
                     im0 = 0.f;
                     im1 = 0.f;
                 }
-                bufA[k] = make_float2(re0 - im1, im0 + re1);
+                bufA[FSW(k)] = make_float2(re0 - im1, im0 + re1);
                 if (k > 0)
-                    bufA[FFT_N - k] = make_float2(re0 + im1, re1 - im0);
+                    bufA[FSW(FFT_N - k)] = make_float2(re0 + im1, re1 - im0);
             }
             if (tid == 0)
-                bufA[2048] = make_float2(0.f, 0.f);
+                bufA[FSW(2048)] = make_float2(0.f, 0.f);
             fetch(f + 1);
             __syncthreads();
-            fft4096<+1>(bufA, bufB, twS, tid); // ends with a barrier: bufA holds the frame
+            fft4096<+1>(bufA, bufB, twS, tid); // ends with a barrier: bufB holds the frame
         }
         const bool emit = t >= t0; // halo frames only build up the ring
         switch (f & 3)
         {
         case 0:
-            istft_ola_step<0>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<0>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
             break;
         case 1:
-            istft_ola_step<1>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<1>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
             break;
         case 2:
-            istft_ola_step<2>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<2>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
             break;
         default:
-            istft_ola_step<3>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<3>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
             break;
         }
-        __syncthreads(); // bufA is rewritten by the next frame
+        __syncthreads(); // bufB is rewritten by the next frame's transform
     }
 }
 
