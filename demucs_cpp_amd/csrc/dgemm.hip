@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
 #pragma unroll
         for (int s = 0; s < S1; ++s)
         {
+#ifdef DMX_ABL_DG_SAMETAP // ablation: every tap reads the centre row (what a register sliding window would leave of the tap traffic)
+            const int in1 = p1 * p.stride1;
+#else
             const int in1 = p1 * p.stride1 + s * p.dil1 - p.pad1;
+#endif
             const bool ok1 = rowOk && in1 >= 0 && in1 < p.L1;
             const float *rowp = xb + (i64)(ok1 ? in1 : 0) * rowLen;
 #pragma unroll
