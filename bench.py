@@ -381,6 +381,9 @@ def main():
                        "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
+                       # the latency point against the same roofline: 340.2 GFLOP in one call vs the fp32 MFMA peak
+                       "single_segment_tflops": None if single_ms is None else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12, 2),
+                       "single_segment_roofline_frac": None if single_ms is None else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12 / PEAK_TFLOPS_FP32_MFMA, 4),
                        "parallelism": f"segment-sharded x{world}"},
         }
         if roofline:

@@ -3,7 +3,7 @@
 # line, rocprofv3 kernel trace of the bench command, PMC passes (each its own run), effective clock, track bench.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out/r02
-( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > gpurun_out/r02/gpu_tests.txt
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 ) > gpurun_out/r02/gpu_tests.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) >> gpurun_out/r02/gpu_tests.txt
 ( timeout 900 python bench.py 2>&1 | grep '^{' ) > gpurun_out/r02/bench_b24.json
 for b in 1 4 12; do ( timeout 600 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --no-track 2>&1 | grep '^{' ) >> gpurun_out/r02/bench_b1_b4_b12.jsonl; done
