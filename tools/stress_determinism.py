@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run-to-run determinism stress at the bench workload: the same batch of 12 full-size segments is pushed
+"""Run-to-run determinism stress at the bench workload: the same batch of full-size segments is pushed
 through the hot path N times; every output must equal the first one bit for bit (a latent LDS race in the
 interleaved K loop or a missing cross-stream join would show up as a mismatch). Also 4 segments (two-stream
 mode) and the 6-source model."""
@@ -16,7 +16,7 @@ from demucs_cpp_amd.weights import write_synthetic_model  # noqa: E402
 SEG = 343980
 N = int(os.environ.get("N", "25"))
 bad = 0
-for ns, B in ((4, 12), (4, 4), (6, 12)):
+for ns, B in ((4, 24), (4, 4), (4, 1), (6, 12)):  # 4 and 1: two-stream mode, graph replay, half-height tiles
     path = f"/tmp/stress_{ns}.bin"
     write_synthetic_model(path, ns, ns)
     m = dmx.Model(path)
