@@ -28,7 +28,7 @@ EXPORTS = [
     "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_ctx_set_stream", "dmx_segment_infer",
     "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
-    "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model",
+    "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_engine_transport", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]

@@ -58,18 +58,47 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
     if (device < 0 || device >= ndev)
         return fail(DMX_ERR_ARG, "dmx_model_load: device %d out of range (have %d)", device, ndev);
     m->device = device;
-    HIPCHK(hipSetDevice(device));
+    m->blobFloats = m->pm.blob.size();
+    DMXCHK(dmx_model_upload(m.get(), m->pm.blob.data()));
+    *out = m.release();
+    return DMX_OK;
+}
+
+int dmx_model_upload(dmx_model *m, const float *blob)
+{
+    HIPCHK(hipSetDevice(m->device));
     // + 1 KB: the igemm staging prefetches two K-tiles (2 x 128 B per row) beyond the last one (never used, must be readable)
-    HIPCHK(hipMalloc((void **)&m->dW, m->pm.blob.size() * sizeof(float) + 1024));
+    HIPCHK(hipMalloc((void **)&m->dW, m->blobFloats * sizeof(float) + 1024));
     // the tail must read as finite numbers (it meets zero activations: 0 x NaN would poison an accumulator)
-    hipError_t e = hipMemset(reinterpret_cast<char *>(m->dW) + m->pm.blob.size() * sizeof(float), 0, 1024);
+    hipError_t e = hipMemset(reinterpret_cast<char *>(m->dW) + m->blobFloats * sizeof(float), 0, 1024);
     if (e == hipSuccess)
-        e = hipMemcpy(m->dW, m->pm.blob.data(), m->pm.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        e = hipMemcpy(m->dW, blob, m->blobFloats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         (void)hipFree(m->dW);
+        m->dW = nullptr;
         return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
     }
+    return DMX_OK;
+}
+
+// Replicates a loaded model onto another device (the weights are packed once per file, not once per GPU).
+extern "C" int dmx_model_clone(const dmx_model *src, int device, dmx_model **out)
+{
+    if (!src || !out)
+        return fail(DMX_ERR_ARG, "dmx_model_clone: null argument");
+    *out = nullptr;
+    if (src->pm.blob.size() != src->blobFloats)
+        return fail(DMX_ERR_ARG, "dmx_model_clone: the source model no longer holds its packed weights on the host");
+    const int ndev = dmx_device_count();
+    if (device < 0 || device >= ndev)
+        return fail(DMX_ERR_ARG, "dmx_model_clone: device %d out of range (have %d)", device, ndev);
+    auto m = std::make_unique<dmx_model>();
+    m->pm.n_sources = src->pm.n_sources, m->pm.dim = src->pm.dim, m->pm.n_tensors = src->pm.n_tensors;
+    m->pm.index = src->pm.index; // offsets only: the plan never reads the host blob
+    m->blobFloats = src->blobFloats;
+    m->device = device;
+    DMXCHK(dmx_model_upload(m.get(), src->pm.blob.data()));
     *out = m.release();
     return DMX_OK;
 }
@@ -215,7 +244,7 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
     if (m == c->m)
         return DMX_OK;
     if (m->device != c->m->device || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
-        m->pm.blob.size() != c->m->pm.blob.size() || m->pm.index != c->m->pm.index)
+        m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
     c->m = m; // kernels of earlier calls hold the old weight pointer by value: no synchronisation needed
     return DMX_OK;

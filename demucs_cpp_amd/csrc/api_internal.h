@@ -30,10 +30,14 @@ void dmx_set_err_string(const std::string &); // adopt an error produced on anot
 
 struct dmx_model
 {
-    dmx::PackedModel pm;
+    dmx::PackedModel pm;    // index / dimensions stay; the packed weights (pm.blob) are kept on the host so that the model
+                            // can be replicated onto further devices (dmx_model_clone) without re-reading the file
+    size_t blobFloats = 0;  // size of the packed weights (also when pm.blob has been released)
     float *dW = nullptr;
     int device = 0;
 };
+// uploads `blob` (blobFloats floats) as the weights of `m` on m->device
+int dmx_model_upload(dmx_model *m, const float *blob);
 
 // grow-only device buffer owned by a context (track-level scratch: allocated on first use, reused by
 // every later call, freed with the context — no hipMalloc/hipFree on the per-track path)

@@ -200,7 +200,10 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
         for (int m = 0; m < n_models; ++m)
         {
             dmx_model *h = nullptr;
-            DMXCHK(dmx_model_load(model_files[m], d.dev, &h));
+            if (l == 0) // parse + pack once per file; the other devices get a copy of the packed weights
+                DMXCHK(dmx_model_load(model_files[m], d.dev, &h));
+            else
+                DMXCHK(dmx_model_clone(e->devs[0].models[(size_t)m], d.dev, &h));
             d.models.push_back(h);
             if (dmx_model_n_sources(h) != dmx_model_n_sources(d.models[0]))
                 return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the models of a bag must have the same number of sources");

@@ -62,6 +62,8 @@ extern "C"
      * tensor name, element-count mismatch) plus "tensor missing". */
     int dmx_model_load(const char *model_file, int device, dmx_model **out);
     void dmx_model_free(dmx_model *m);
+    /* the same weights on another device, without re-reading / re-packing the file (one replica per GPU) */
+    int dmx_model_clone(const dmx_model *src, int device, dmx_model **out);
     int dmx_model_n_sources(const dmx_model *m); /* 4 or 6 (demucs_model::is_4sources) */
     int dmx_model_n_tensors(const dmx_model *m);
     int dmx_model_device(const dmx_model *m);
