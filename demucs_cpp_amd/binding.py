@@ -30,10 +30,11 @@ EXPORTS = [
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
-    "dmx_engine_transport", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
+    "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2
+FINISH_ROOT, FINISH_OWNER = 0, 1
 
 _lib = None
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_float, ctypes.c_char_p, ctypes.c_void_p)
@@ -89,7 +90,8 @@ def lib():
         L.dmx_ctx_set_model.argtypes = [vp, vp]
         L.dmx_engine_create.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, ctypes.POINTER(ci), ci, ci, ci, ctypes.POINTER(vp)]
         L.dmx_engine_free.argtypes = [vp]
-        for f in ("dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources", "dmx_engine_transport"):
+        L.dmx_engine_set_finish.argtypes = [vp, ci]
+        for f in ("dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources", "dmx_engine_transport", "dmx_engine_finish"):
             getattr(L, f).argtypes = [vp]
         L.dmx_engine_root_ctx.argtypes = [vp, ci]
         L.dmx_engine_root_ctx.restype = vp
@@ -255,7 +257,7 @@ class Engine:
     """Several GPUs and / or a bag of models in one process (csrc/engine.cpp): demucs_inference with the
     (model, segment) items sharded over `devices`; `devices` may repeat an id (logical devices on one GPU)."""
 
-    def __init__(self, model_files, devices=None, max_batch: int = 4, transport: int = TRANSPORT_AUTO):
+    def __init__(self, model_files, devices=None, max_batch: int = 4, transport: int = TRANSPORT_AUTO, finish: Optional[int] = None):
         files = (ctypes.c_char_p * len(model_files))(*[f.encode() for f in model_files])
         devs = (ctypes.c_int * len(devices))(*devices) if devices else None
         self.h = ctypes.c_void_p()
@@ -265,6 +267,17 @@ class Engine:
         self.n_models = lib().dmx_engine_n_models(self.h)
         self.n_devices = lib().dmx_engine_n_devices(self.h)
         self.transport = lib().dmx_engine_transport(self.h)
+        if finish is not None:
+            self.set_finish(finish)
+
+    def set_finish(self, finish: int):
+        """FINISH_ROOT: blocks gathered and overlap-added on the first device; FINISH_OWNER: every device finishes
+        the stretch of the track its segments cover (only segment tails are exchanged). Same bits."""
+        _chk(lib().dmx_engine_set_finish(self.h, finish))
+
+    @property
+    def finish(self) -> int:
+        return lib().dmx_engine_finish(self.h)
 
     def close(self):
         if self.h:
@@ -277,16 +290,28 @@ class Engine:
         except Exception:
             pass
 
-    def track(self, audio: np.ndarray, shift_offsets, progress=None, out: Optional[np.ndarray] = None) -> np.ndarray:
-        """audio (2, n) planar -> (S, 2, n); one shift offset per model. `out`: reuse a result buffer."""
+    def track(self, audio: np.ndarray, shift_offsets, progress=None, out: Optional[np.ndarray] = None,
+              layout: int = LAYOUT_PLANAR) -> np.ndarray:
+        """audio (2, n) planar -> (S, 2, n); one shift offset per model. `out`: reuse a result buffer.
+        layout=LAYOUT_EIGEN passes the track and receives the result through the C ABI as Eigen column-major
+        images (what the C++ shim does); the arrays seen by the caller are the same."""
         audio = np.ascontiguousarray(audio, np.float32)
         n = audio.shape[1]
-        if out is None:
-            out = np.zeros((self.S, 2, n), np.float32)
-        assert out.shape == (self.S, 2, n) and out.dtype == np.float32 and out.flags.c_contiguous
         so = (ctypes.c_int * self.n_models)(*shift_offsets)
         cb = PROGRESS_FN(lambda p, m, u: progress(p, m.decode())) if progress else None
         cbp = ctypes.cast(cb, ctypes.c_void_p) if cb else None
+        if layout == LAYOUT_EIGEN:
+            a = np.ascontiguousarray(audio.T)  # [n][2] == column-major 2 x n
+            img = np.zeros((n, 2, self.S), np.float32)  # flat index s + S*(c + 2*i)
+            _chk(lib().dmx_engine_track_infer(self.h, a.ctypes.data, n, so, img.ctypes.data, LAYOUT_EIGEN, cbp, None))
+            res = np.ascontiguousarray(img.transpose(2, 1, 0))
+            if out is not None:
+                out[...] = res
+                return out
+            return res
+        if out is None:
+            out = np.zeros((self.S, 2, n), np.float32)
+        assert out.shape == (self.S, 2, n) and out.dtype == np.float32 and out.flags.c_contiguous
         _chk(lib().dmx_engine_track_infer(self.h, audio.ctypes.data, n, so, out.ctypes.data, LAYOUT_PLANAR, cbp, None))
         return out
 

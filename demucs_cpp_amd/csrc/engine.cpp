@@ -25,6 +25,13 @@
 //     each output sample accumulates its <= 2 covering segments in increasing index), takes stem m from
 //     model m for a bag, de-normalises and copies out.
 //
+// Optional finish mode OWNER (dmx_engine_set_finish / env DMX_FINISH=owner): instead of gathering whole segment
+// blocks on the root, the owner of the contiguous run [g0, g1) also FINISHES the output stretch
+// [g0*stride, g1*stride) of the shifted track: the only data it lacks is the tail [stride, segment) of
+// segment g0-1 (S*2*(segment-stride) floats = 2.75 MB against 11 MB per gathered block and 231 MB per
+// gathered 4-minute track), which the previous owner sends (ncclSend/ncclRecv or a peer copy); every
+// device overlap-adds and copies out its own stretch. Same accumulation order per sample, same bits.
+//
 // librccl is bound lazily with dlopen the first time an RCCL engine is created: single-device users and
 // torch.distributed processes (which bring their own copy) never load a second RCCL.
 #include "api_internal.h"
@@ -99,7 +106,10 @@ struct EngineDev
     int dev = 0;                     // HIP device id (several logical devices may share one)
     std::vector<dmx_model *> models; // replica of every model on this device
     dmx_ctx *ctx = nullptr;          // one arena, rebound to the model of the run (dmx_ctx_set_model)
-    DevBuf slab;                     // results of this device's items (non-root devices)
+    DevBuf slab;                     // results of this device's items (non-root devices; every device in OWNER mode)
+    DevBuf haloSend, haloRecv;       // OWNER mode: packed tails [stride, seg) of boundary segments, one slot per run
+    float *pinned = nullptr;         // OWNER mode: pinned staging of this device's finished stretches
+    i64 pinnedCap = 0;
     ncclComm_t comm = nullptr;
     hipEvent_t evDone = nullptr;
     // result of the last call's worker
@@ -109,7 +119,7 @@ struct EngineDev
 
 struct dmx_engine
 {
-    int nModels = 0, S = 0, maxBatch = 0, transport = DMX_TRANSPORT_P2P;
+    int nModels = 0, S = 0, maxBatch = 0, transport = DMX_TRANSPORT_P2P, finish = DMX_FINISH_ROOT;
     i64 seg = 0;
     std::vector<EngineDev> devs;
     std::vector<DevBuf> segOut; // root: per model [n_seg][S][2][seg]
@@ -127,8 +137,11 @@ struct dmx_engine
             if (d.evDone)
                 (void)hipEventDestroy(d.evDone);
             delete d.ctx; // before the models it points to
-            if (d.slab.p)
-                (void)hipFree(d.slab.p);
+            if (d.pinned)
+                (void)hipHostFree(d.pinned);
+            for (DevBuf *b : {&d.slab, &d.haloSend, &d.haloRecv})
+                if (b->p)
+                    (void)hipFree(b->p);
             for (dmx_model *m : d.models)
                 dmx_model_free(m);
         }
@@ -224,18 +237,29 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
                         n_models, e->S);
     e->segOut.resize((size_t)n_models);
     if (devs.size() > 1 && distinct)
-        for (size_t l = 1; l < devs.size(); ++l) // direct xGMI copies between the root and every peer
-        {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devs[l], devs[0]) == hipSuccess && can)
+        for (size_t l = 0; l < devs.size(); ++l) // direct xGMI copies: every device to the root (gather) and to
+            for (size_t q = 0; q < devs.size(); ++q) // the later devices (halo of the OWNER finish mode)
             {
-                (void)hipSetDevice(devs[l]);
-                hipError_t pe = hipDeviceEnablePeerAccess(devs[0], 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-                    return dmx_fail(DMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", devs[l], devs[0], hipGetErrorString(pe));
-                (void)hipGetLastError();
+                if (q == l || (q != 0 && q < l))
+                    continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[l], devs[q]) == hipSuccess && can)
+                {
+                    (void)hipSetDevice(devs[l]);
+                    hipError_t pe = hipDeviceEnablePeerAccess(devs[q], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                        return dmx_fail(DMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", devs[l], devs[q],
+                                        hipGetErrorString(pe));
+                    (void)hipGetLastError();
+                }
             }
-        }
+    if (const char *env = getenv("DMX_FINISH"))
+    {
+        if (!strcmp(env, "owner"))
+            e->finish = DMX_FINISH_OWNER;
+        else if (strcmp(env, "root"))
+            return dmx_fail(DMX_ERR_ARG, "DMX_FINISH must be root or owner (is \"%s\")", env);
+    }
     if (transport == DMX_TRANSPORT_RCCL)
     {
         RcclApi *api = rccl_api();
@@ -255,6 +279,15 @@ extern "C" int dmx_engine_n_devices(const dmx_engine *e) { return e ? (int)e->de
 extern "C" int dmx_engine_n_models(const dmx_engine *e) { return e ? e->nModels : 0; }
 extern "C" int dmx_engine_n_sources(const dmx_engine *e) { return e ? e->S : 0; }
 extern "C" int dmx_engine_transport(const dmx_engine *e) { return e ? e->transport : -1; }
+extern "C" int dmx_engine_finish(const dmx_engine *e) { return e ? e->finish : -1; }
+extern "C" int dmx_engine_set_finish(dmx_engine *e, int finish)
+{
+    if (!e || (finish != DMX_FINISH_ROOT && finish != DMX_FINISH_OWNER))
+        return dmx_fail(DMX_ERR_ARG, "dmx_engine_set_finish: invalid argument");
+    std::lock_guard<std::mutex> guard(e->mu);
+    e->finish = finish;
+    return DMX_OK;
+}
 extern "C" dmx_ctx *dmx_engine_root_ctx(dmx_engine *e, int model)
 {
     if (!e || model < 0 || model >= e->nModels)
@@ -269,7 +302,11 @@ namespace
 struct Run // a maximal stretch of one device's items that belongs to one model
 {
     int model, g0, g1;  // segments [g0, g1) of `model`
-    i64 slabOff;        // float offset of the run's results in the device's slab
+    i64 slabOff;        // offset (in segment blocks) of the run's results in the device's slab
+    // OWNER finish mode
+    i64 ownSlot = 0;            // block index of segment g0 in the slab (the block before it is the halo when g0 > 0)
+    int predDev = -1, predRun = -1; // who computes segment g0-1 of this model
+    int succDev = -1, succRun = -1; // who computes segment g1
 };
 struct Shared
 {
@@ -278,6 +315,9 @@ struct Shared
     int itemsDone = 0;
     int workersLeft = 0;
     std::vector<std::string> messages; // progress lines waiting for the calling thread
+    // OWNER finish mode, peer-copy transport: haloReady[l][ri] is set by the sender once its copy has landed
+    std::vector<std::vector<char>> haloReady;
+    bool failed = false; // a worker gave up: receivers stop waiting
 };
 } // namespace
 
@@ -326,6 +366,29 @@ extern "C" int dmx_engine_partition(const int *n_segments, int n_models, int n_d
     return DMX_OK;
 }
 
+// upload of the track + its statistics (every device holds the small track and computes the same numbers)
+static int upload_track(dmx_ctx *c, const float *audio, int layout, i64 n)
+{
+    if (layout == DMX_LAYOUT_EIGEN)
+        HIPCHK(hipMemcpyAsync(c->bAudio.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    else
+    {
+        HIPCHK(hipMemcpyAsync(c->bTmp.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        launch_planar_to_interleaved(c->bTmp.p, c->bAudio.p, n, c->stream);
+    }
+    return dmx_track_stats_device(c, c->bAudio.p, n, c->dStats);
+}
+
+static void post_progress(Shared &sh, int items, int l, int dev)
+{
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.itemsDone += items;
+    char msg[160];
+    snprintf(msg, sizeof(msg), "2., apply model w/ split, device %d (gpu %d) finished %d segments", l, dev, items);
+    sh.messages.push_back(msg);
+    sh.cv.notify_all();
+}
+
 // what logical device l does for one track (on its own host thread)
 static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64 n, const std::vector<int> &shifts,
                        const std::vector<int> &nseg, const std::vector<Run> &runs, const std::vector<std::vector<Run>> &allRuns,
@@ -338,15 +401,7 @@ static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64
     HIPCHK(hipSetDevice(d.dev));
     if (!runs.empty() || l == 0)
     {
-        // every device holds the (small) track and computes the same statistics locally
-        if (layout == DMX_LAYOUT_EIGEN)
-            HIPCHK(hipMemcpyAsync(c->bAudio.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        else
-        {
-            HIPCHK(hipMemcpyAsync(c->bTmp.p, audio, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-            launch_planar_to_interleaved(c->bTmp.p, c->bAudio.p, n, c->stream);
-        }
-        DMXCHK(dmx_track_stats_device(c, c->bAudio.p, n, c->dStats));
+        DMXCHK(upload_track(c, audio, layout, n));
     }
     std::vector<int> idx;
     size_t nev = 0;
@@ -401,14 +456,152 @@ static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64
     for (size_t k = 0; k < nev; ++k)
     {
         HIPCHK(hipEventSynchronize(c->batchEvents[k]));
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.itemsDone += evItems[k];
-        char msg[160];
-        snprintf(msg, sizeof(msg), "2., apply model w/ split, device %d (gpu %d) finished %d segments", l, d.dev, evItems[k]);
-        sh.messages.push_back(msg);
-        sh.cv.notify_all();
+        post_progress(sh, evItems[k], l, d.dev);
     }
     HIPCHK(hipStreamSynchronize(c->stream)); // the slab has reached the root (or the root has received every slab)
+    return DMX_OK;
+}
+
+// OWNER finish mode: what logical device l does for one track. The device computes its runs, sends the
+// tail of each run's last segment to the owner of the next segment, receives the tail in front of each
+// of its runs, overlap-adds the stretch [g0*stride, g1*stride) of every run and copies it into `out`.
+static int device_work_owner(dmx_engine *e, int l, const float *audio, int layout, i64 n, const std::vector<int> &shifts,
+                             const std::vector<int> &nseg, const std::vector<i64> &lens, i64 stride,
+                             const std::vector<std::vector<Run>> &allRuns, float *out, Shared &sh)
+{
+    EngineDev &d = e->devs[(size_t)l];
+    dmx_ctx *c = d.ctx;
+    const std::vector<Run> &runs = allRuns[(size_t)l];
+    const int S = e->S, M = e->nModels;
+    const i64 seg = e->seg, blk = (i64)S * 2 * seg, tail = seg - stride, halo = (i64)S * 2 * tail;
+    if (runs.empty())
+        return DMX_OK;
+    HIPCHK(hipSetDevice(d.dev));
+    DMXCHK(upload_track(c, audio, layout, n));
+    std::vector<int> idx, evItems;
+    size_t nev = 0;
+    for (const Run &r : runs)
+    {
+        DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
+        float *dst = d.slab.p + r.ownSlot * blk;
+        for (int g = r.g0; g < r.g1; g += e->maxBatch)
+        {
+            const int nb = std::min(e->maxBatch, r.g1 - g);
+            idx.resize((size_t)nb);
+            for (int i = 0; i < nb; ++i)
+                idx[(size_t)i] = g + i;
+            DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
+            DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
+            hipEvent_t ev = dmx_batch_event(c, nev++);
+            if (!ev)
+                return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
+            HIPCHK(hipEventRecord(ev, c->stream));
+            evItems.push_back(nb);
+        }
+    }
+    // ---- the exchange step: tails [stride, seg) of the boundary segments, packed to S*2 rows of `tail` floats
+    const bool rccl = e->transport == DMX_TRANSPORT_RCCL;
+    for (size_t ri = 0; ri < runs.size(); ++ri)
+        if (runs[ri].succDev >= 0)
+            launch_copy_rows(d.haloSend.p + (i64)ri * halo, tail, d.slab.p + (runs[ri].ownSlot + (runs[ri].g1 - 1 - runs[ri].g0)) * blk + stride,
+                             seg, tail, S * 2, c->stream);
+    HIPCHK(hipGetLastError());
+    if (rccl)
+    {
+        RcclApi *api = rccl_api();
+        NCCLCHK(api->GroupStart());
+        for (size_t ri = 0; ri < runs.size(); ++ri)
+        {
+            if (runs[ri].succDev >= 0)
+                NCCLCHK(api->Send(d.haloSend.p + (i64)ri * halo, (size_t)halo, kNcclFloat, runs[ri].succDev, d.comm, c->stream));
+            if (runs[ri].predDev >= 0)
+                NCCLCHK(api->Recv(d.haloRecv.p + (i64)ri * halo, (size_t)halo, kNcclFloat, runs[ri].predDev, d.comm, c->stream));
+        }
+        NCCLCHK(api->GroupEnd());
+    }
+    else
+    {
+        for (size_t ri = 0; ri < runs.size(); ++ri)
+            if (runs[ri].succDev >= 0)
+            {
+                EngineDev &q = e->devs[(size_t)runs[ri].succDev];
+                HIPCHK(hipMemcpyPeerAsync(q.haloRecv.p + (i64)runs[ri].succRun * halo, q.dev, d.haloSend.p + (i64)ri * halo, d.dev,
+                                          sizeof(float) * (size_t)halo, c->stream));
+            }
+    }
+    // ---- progress: one line per finished batch, delivered by the calling thread
+    for (size_t k = 0; k < nev; ++k)
+    {
+        HIPCHK(hipEventSynchronize(c->batchEvents[k]));
+        post_progress(sh, evItems[k], l, d.dev);
+    }
+    if (!rccl)
+    {
+        HIPCHK(hipStreamSynchronize(c->stream)); // my tails have landed at their receivers
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            for (const Run &r : runs)
+                if (r.succDev >= 0)
+                    sh.haloReady[(size_t)r.succDev][(size_t)r.succRun] = 1;
+            sh.cv.notify_all();
+        }
+        std::unique_lock<std::mutex> lk(sh.mu);
+        for (size_t ri = 0; ri < runs.size(); ++ri)
+            if (runs[ri].predDev >= 0)
+            {
+                sh.cv.wait(lk, [&] { return sh.haloReady[(size_t)l][ri] || sh.failed; });
+                if (!sh.haloReady[(size_t)l][ri])
+                    return dmx_fail(DMX_ERR_HIP, "device %d: the owner of the previous segment failed", l);
+            }
+    }
+    // ---- finish my stretches
+    struct Piece
+    {
+        i64 stage, dst, len, pitch;
+        int rows;
+    };
+    std::vector<Piece> pieces;
+    i64 stageFloats = 0;
+    for (size_t ri = 0; ri < runs.size(); ++ri)
+    {
+        const Run &r = runs[ri];
+        const int m = r.model;
+        if (r.predDev >= 0) // unpack the received tail into the block in front of the run (segment g0-1)
+            launch_copy_rows(d.slab.p + (r.ownSlot - 1) * blk + stride, seg, d.haloRecv.p + (i64)ri * halo, tail, tail, S * 2, c->stream);
+        // positions [g0*stride, g1*stride) of the shifted track (to its end for the last run), as samples of the result
+        const i64 off = DMX_MAX_SHIFT - shifts[(size_t)m];
+        const i64 j1 = r.g1 == nseg[(size_t)m] ? lens[(size_t)m] : (i64)r.g1 * stride;
+        const i64 i0 = std::min(n, std::max<i64>(0, (i64)r.g0 * stride - off)), i1 = std::min(n, std::max<i64>(0, j1 - off));
+        if (i1 <= i0)
+            continue;
+        const int gBase = r.predDev >= 0 ? r.g0 - 1 : r.g0;
+        const int p0 = M == 1 ? 0 : 2 * m, np = M == 1 ? 2 * S : 2;
+        launch_track_ola(d.slab.p + (r.ownSlot - (r.g0 - gBase)) * blk, nseg[(size_t)m], S, seg, stride, lens[(size_t)m], n,
+                         shifts[(size_t)m], c->dStats, c->bOut.p, layout == DMX_LAYOUT_EIGEN ? 1 : 0, p0, np, i0, i1, c->stream, gBase);
+        HIPCHK(hipGetLastError());
+        // D2H into this device's pinned staging buffer (G devices write one pageable result concurrently: each
+        // through its own DMA into its own pinned pages, then a host copy into the disjoint range it owns)
+        Piece pc;
+        pc.stage = stageFloats;
+        if (layout == DMX_LAYOUT_EIGEN) // (only with M == 1: all planes of the samples [i0, i1) are contiguous)
+        {
+            pc.dst = (i64)2 * S * i0, pc.len = (i64)2 * S * (i1 - i0), pc.rows = 1, pc.pitch = 0;
+            HIPCHK(hipMemcpyAsync(d.pinned + pc.stage, c->bOut.p + pc.dst, sizeof(float) * (size_t)pc.len, hipMemcpyDeviceToHost, c->stream));
+        }
+        else
+        {
+            pc.dst = (i64)p0 * n + i0, pc.len = i1 - i0, pc.rows = np, pc.pitch = n;
+            for (int pl = 0; pl < np; ++pl)
+                HIPCHK(hipMemcpyAsync(d.pinned + pc.stage + (i64)pl * pc.len, c->bOut.p + pc.dst + (i64)pl * n, sizeof(float) * (size_t)pc.len,
+                                      hipMemcpyDeviceToHost, c->stream));
+        }
+        stageFloats += pc.len * pc.rows;
+        pieces.push_back(pc);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (const Piece &pc : pieces)
+        for (int r = 0; r < pc.rows; ++r)
+            memcpy(out + pc.dst + (i64)r * pc.pitch, d.pinned + pc.stage + (i64)r * pc.len, sizeof(float) * (size_t)pc.len);
     return DMX_OK;
 }
 
@@ -441,6 +634,28 @@ extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t
     }
     std::vector<std::vector<Run>> runs;
     partition(nseg, G, runs);
+    // the per-stem D2H of the OWNER mode needs each stem's samples contiguous: a bag in the Eigen image is finished on the root
+    const bool owner = e->finish == DMX_FINISH_OWNER && G > 1 && (M == 1 || layout == DMX_LAYOUT_PLANAR);
+    if (owner)
+        for (int l = 0; l < G; ++l)
+        {
+            i64 slot = 0;
+            for (size_t ri = 0; ri < runs[(size_t)l].size(); ++ri)
+            {
+                Run &r = runs[(size_t)l][ri];
+                for (int q = l - 1; q >= 0 && r.g0 > 0 && r.predDev < 0; --q) // who owns segment g0-1 of this model
+                    for (size_t rj = 0; rj < runs[(size_t)q].size(); ++rj)
+                        if (runs[(size_t)q][rj].model == r.model && runs[(size_t)q][rj].g1 == r.g0)
+                        {
+                            r.predDev = q, r.predRun = (int)rj;
+                            runs[(size_t)q][rj].succDev = l, runs[(size_t)q][rj].succRun = (int)ri;
+                        }
+                if (r.g0 > 0 && r.predDev < 0)
+                    return dmx_fail(DMX_ERR_ARG, "dmx_engine_track_infer: internal error (segment %d of model %d has no owner)", r.g0 - 1, r.model);
+                r.ownSlot = slot + (r.predDev >= 0 ? 1 : 0);
+                slot = r.ownSlot + (r.g1 - r.g0);
+            }
+        }
     // ---- buffers (grown on first use, reused afterwards)
     for (int l = 0; l < G; ++l)
     {
@@ -452,7 +667,31 @@ extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t
         if (layout == DMX_LAYOUT_PLANAR)
             DMXCHK(dmx_ensure_buf(d.ctx->bTmp, 2 * n));
         DMXCHK(dmx_ensure_buf(d.ctx->bMix, 2 * seg * e->maxBatch));
-        if (l != 0)
+        if (owner)
+        {
+            const std::vector<Run> &rl = runs[(size_t)l];
+            const i64 halo = (i64)S * 2 * (seg - stride);
+            if (!rl.empty())
+            {
+                DMXCHK(dmx_ensure_buf(d.slab, (rl.back().ownSlot + (rl.back().g1 - rl.back().g0)) * blk));
+                DMXCHK(dmx_ensure_buf(d.haloSend, (i64)rl.size() * halo));
+                DMXCHK(dmx_ensure_buf(d.haloRecv, (i64)rl.size() * halo));
+                DMXCHK(dmx_ensure_buf(d.ctx->bOut, (i64)S * 2 * n));
+                // staging for the stretches this device finishes: <= (its share of a model's planes) x (its positions + slack)
+                i64 need = 0;
+                for (const Run &r : rl)
+                    need += (i64)(M == 1 ? 2 * S : 2) * std::min<i64>(n, (i64)(r.g1 - r.g0) * stride + seg);
+                if (need > d.pinnedCap)
+                {
+                    if (d.pinned)
+                        HIPCHK(hipHostFree(d.pinned));
+                    d.pinned = nullptr, d.pinnedCap = 0;
+                    HIPCHK(hipHostMalloc((void **)&d.pinned, sizeof(float) * (size_t)need, hipHostMallocDefault));
+                    d.pinnedCap = need;
+                }
+            }
+        }
+        else if (l != 0)
         {
             i64 items = 0;
             for (const Run &r : runs[(size_t)l])
@@ -461,23 +700,32 @@ extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t
         }
     }
     HIPCHK(hipSetDevice(e->devs[0].dev));
-    for (int m = 0; m < M; ++m)
-        DMXCHK(dmx_ensure_buf(e->segOut[(size_t)m], (i64)nseg[(size_t)m] * blk));
-    DMXCHK(dmx_ensure_buf(e->out, (i64)S * 2 * n));
+    if (!owner)
+    {
+        for (int m = 0; m < M; ++m)
+            DMXCHK(dmx_ensure_buf(e->segOut[(size_t)m], (i64)nseg[(size_t)m] * blk));
+        DMXCHK(dmx_ensure_buf(e->out, (i64)S * 2 * n));
+    }
     if (progress)
         progress(0.0f, "1., apply model w/ shift", user);
     // ---- one host thread per device; this thread delivers the progress lines (the reference invokes the
     // callback synchronously on the caller's thread, src/model.hpp:17)
     Shared sh;
     sh.workersLeft = G;
+    sh.haloReady.resize((size_t)G);
+    for (int l = 0; l < G; ++l)
+        sh.haloReady[(size_t)l].assign(runs[(size_t)l].size(), 0);
     std::vector<std::thread> threads;
     for (int l = 0; l < G; ++l)
         threads.emplace_back([&, l] {
             EngineDev &d = e->devs[(size_t)l];
-            d.rc = device_work(e, l, audio, layout, n, shifts, nseg, runs[(size_t)l], runs, sh);
+            d.rc = owner ? device_work_owner(e, l, audio, layout, n, shifts, nseg, lens, stride, runs, out, sh)
+                         : device_work(e, l, audio, layout, n, shifts, nseg, runs[(size_t)l], runs, sh);
             d.err = d.rc == DMX_OK ? std::string() : dmx_err_string();
             std::lock_guard<std::mutex> lk(sh.mu);
             --sh.workersLeft;
+            if (d.rc != DMX_OK)
+                sh.failed = true;
             sh.cv.notify_all();
         });
     {
@@ -506,6 +754,8 @@ extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t
             dmx_set_err_string("device " + std::to_string(l) + ": " + e->devs[(size_t)l].err);
             return e->devs[(size_t)l].rc;
         }
+    if (owner) // every device has finished and copied out its own stretch
+        return DMX_OK;
     // ---- root: overlap-add per model in segment order, stem m from model m for a bag
     // (model_apply.cpp:171-246; demucs_ft.cpp:238-241), de-normalise, copy out
     EngineDev &r0 = e->devs[0];

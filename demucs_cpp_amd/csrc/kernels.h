@@ -171,8 +171,13 @@ void launch_track_gather(const float *audio, i64 n, const float *stats, int shif
 // overlap-add of nSeg segment outputs [nSeg][S][2][seg] (segment ids 0..nSeg-1) into planes
 // [planeBase, planeBase + nPlanes) (plane = stem*2 + channel) and samples [i0, i1) of out.
 // layout 0: planar [S][2][n]; layout 1: Eigen column-major image (s + S*(c + 2*i))
+// gBase: segOut[0] is segment gBase (a device that holds only a stretch of the segments; every segment the
+// samples [i0, i1) touch must be in the buffer)
 void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len, i64 n, int shiftOffset,
-                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s);
+                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s,
+                      int gBase = 0);
+// dst[r*dpitch + i] = src[r*spitch + i], r < rows, i < width (floats)
+void launch_copy_rows(float *dst, i64 dpitch, const float *src, i64 spitch, i64 width, int rows, hipStream_t s);
 // interleaved <-> planar helpers
 void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream_t s);
 

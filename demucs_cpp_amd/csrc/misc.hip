@@ -354,7 +354,7 @@ void launch_track_gather(const float *audio, i64 n, const float *stats, int shif
 // as soon as the segments covering a piece are done.
 __global__ __launch_bounds__(256) void track_ola_kernel(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len,
                                                         i64 n, int shiftOffset, const float *stats, float *out, int layout,
-                                                        int planeBase, i64 i0, i64 i1)
+                                                        int planeBase, i64 i0, i64 i1, int gBase)
 {
     const int plane = blockIdx.y + planeBase;
     const float mean = stats[0], stdv = stats[1];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void track_ola_kernel(const float *segOut, int
             // triangle weight, indexed from 0 even for short chunks (Q8)
             const i64 kk = k < seg / 2 ? k + 1 : seg - k;
             const float w = (float)kk / half;
-            acc += w * segOut[((i64)g * S * 2 + plane) * seg + left + k];
+            acc += w * segOut[((i64)(g - gBase) * S * 2 + plane) * seg + left + k]; // segOut[0] holds segment gBase
             sw += w;
         }
         const float v = (acc / sw) * stdv + mean;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void track_ola_kernel(const float *segOut, int
     }
 }
 void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride, i64 len, i64 n, int shiftOffset,
-                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s)
+                      const float *stats, float *out, int layout, int planeBase, int nPlanes, i64 i0, i64 i1, hipStream_t s, int gBase)
 {
     if (i1 <= i0 || nPlanes <= 0)
         return;
@@ -400,7 +400,24 @@ void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride,
     if (gx > 4096)
         gx = 4096;
     hipLaunchKernelGGL(track_ola_kernel, dim3(gx, nPlanes), dim3(256), 0, s, segOut, nSeg, S, seg, stride, len, n, shiftOffset,
-                       stats, out, layout, planeBase, i0, i1);
+                       stats, out, layout, planeBase, i0, i1, gBase);
+}
+
+// rows x width floats between two pitched images (packing / unpacking the segment tails the OWNER finish mode exchanges)
+__global__ __launch_bounds__(256) void copy_rows_kernel(float *dst, i64 dpitch, const float *src, i64 spitch, i64 width)
+{
+    const i64 r = blockIdx.y;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < width; i += (i64)gridDim.x * 256)
+        dst[r * dpitch + i] = src[r * spitch + i];
+}
+void launch_copy_rows(float *dst, i64 dpitch, const float *src, i64 spitch, i64 width, int rows, hipStream_t s)
+{
+    if (width <= 0 || rows <= 0)
+        return;
+    int gx = (int)((width + 255) / 256);
+    if (gx > 1024)
+        gx = 1024;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(gx, rows), dim3(256), 0, s, dst, dpitch, src, spitch, width);
 }
 
 __global__ void planar_to_interleaved_kernel(const float *src, float *dst, i64 n)

@@ -153,6 +153,18 @@ extern "C"
     int dmx_engine_n_models(const dmx_engine *e);
     int dmx_engine_n_sources(const dmx_engine *e);
     int dmx_engine_transport(const dmx_engine *e);
+    /* where a track is finished (overlap-add, de-normalisation, copy-out). Same bits either way.
+     *   DMX_FINISH_ROOT  (default): every device's segment blocks are gathered on the first device, which
+     *                    overlap-adds the track - the reference's structure (model_apply.cpp:207-246) with
+     *                    the gather SURVEY.md section 8e names;
+     *   DMX_FINISH_OWNER (env DMX_FINISH=owner): the owner of segments [g0, g1) finishes the stretch
+     *                    [g0*stride, g1*stride) itself; only the tail of segment g0-1 crosses the link
+     *                    (2.75 MB instead of 11 MB per segment), and G devices copy out in parallel.
+     *                    A bag in the Eigen layout is still finished on the root. */
+#define DMX_FINISH_ROOT 0
+#define DMX_FINISH_OWNER 1
+    int dmx_engine_set_finish(dmx_engine *e, int finish);
+    int dmx_engine_finish(const dmx_engine *e);
     /* the root device's context bound to model `model` (segment-level calls: dmx_segment_infer*) */
     dmx_ctx *dmx_engine_root_ctx(dmx_engine *e, int model);
     /* shift_offsets: one per model (NULL or -1 entries: rand() % 22050 drawn in model order, like the

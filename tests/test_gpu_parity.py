@@ -457,6 +457,55 @@ def test_engine_ft_bag_equals_four_sequential_runs_bitwise(dmx, tmp_path):
         dmx.Engine(paths[:2], [0])
 
 
+def test_engine_owner_finish_mode_equals_root_gather_bitwise(dmx, tmp_models, tmp_path):
+    """DMX_FINISH_OWNER: the owner of segments [g0, g1) overlap-adds and copies out the stretch of the track they
+    cover; only the tail of segment g0-1 is exchanged. Same accumulation order per sample as the root's
+    overlap-add, so the same bits - for a plain model in both layouts (2 and 3 logical devices, runs of
+    different lengths, a device with a single segment) and for the bag (runs that straddle models)."""
+    from demucs_cpp_amd.weights import write_synthetic_model
+    stride = 257985
+    n = 4 * stride + 1000  # 5 segments
+    audio = (0.1 * np.random.default_rng(47).standard_normal((2, n)) - 0.03).astype(np.float32)
+    m = dmx.Model(tmp_models[6]); ctx = dmx.Context(m, 0, 2)
+    ref = ctx.track(audio, 4033)
+    ref0 = ctx.track(audio, 0)  # offset 0: the first samples of the result come from inside segment 0
+    ctx.close(); m.close()
+    for devs in ([0, 0], [0, 0, 0], [0] * 5):
+        eng = dmx.Engine([tmp_models[6]], devs, max_batch=2, finish=dmx.FINISH_OWNER)
+        assert eng.finish == dmx.FINISH_OWNER
+        msgs = []
+        got = eng.track(audio, [4033], progress=lambda p, s: msgs.append(p))
+        assert np.array_equal(got, ref)
+        assert msgs and abs(max(msgs) - 1.0) < 1e-6
+        assert np.array_equal(eng.track(audio, [4033], layout=dmx.LAYOUT_EIGEN), ref)
+        assert np.array_equal(eng.track(audio, [0]), ref0)
+        eng.set_finish(dmx.FINISH_ROOT)
+        assert np.array_equal(eng.track(audio, [4033], layout=dmx.LAYOUT_EIGEN), ref)
+        eng.close()
+    # more devices than segments: the idle devices do nothing
+    short = audio[:, : stride // 2]
+    m = dmx.Model(tmp_models[6]); ctx = dmx.Context(m, 0, 1)
+    ref_s = ctx.track(short, 100)
+    ctx.close(); m.close()
+    eng = dmx.Engine([tmp_models[6]], [0, 0, 0], max_batch=1, finish=dmx.FINISH_OWNER)
+    assert np.array_equal(eng.track(short, [100]), ref_s)
+    eng.close()
+    # the bag
+    paths = []
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        p = str(tmp_path / f"ggml-model-htdemucs_ft_{name}-4s-f16.bin")
+        write_synthetic_model(p, 4, 60 + i)
+        paths.append(p)
+    nb = 2 * stride + 5000
+    a2 = audio[:, :nb]
+    eng = dmx.Engine(paths, [0, 0, 0], max_batch=3)
+    want = eng.track(a2, list(SHIFTS_GLIBC))
+    eng.set_finish(dmx.FINISH_OWNER)
+    assert np.array_equal(eng.track(a2, list(SHIFTS_GLIBC)), want)
+    assert np.array_equal(eng.track(a2, list(SHIFTS_GLIBC), layout=dmx.LAYOUT_EIGEN), want)  # finished on the root
+    eng.close()
+
+
 def test_engine_rccl_transport_binds_and_builds_a_communicator(dmx, tmp_models):
     """The RCCL transport (ncclCommInitAll / ncclSend / grouped ncclRecv, bound with dlopen) on the one GPU of
     this box: the library loads, every symbol resolves, a communicator is built and destroyed, and a bag run
