@@ -225,6 +225,7 @@ class Context:
     def profile(self, batch: int = 1, reps: int = 3):
         """[(op name, kernel, ms per launch, algorithmic flops, algorithmic bytes)]"""
         cap = 1 << 17
+        self.profile_geometry = {}
         buf = ctypes.create_string_buffer(cap)
         n = lib().dmx_debug_profile(self.h, batch, reps, buf, cap)
         if n < 0:
@@ -233,8 +234,9 @@ class Context:
         for ln in buf.value.decode().split("\n"):
             if not ln:
                 continue
-            nm, k, ms, fl, by = ln.split("\t")
+            nm, k, ms, fl, by = ln.split("\t")[:5]
             rows.append((nm, k, float(ms), float(fl), float(by)))
+            self.profile_geometry[nm] = ln.split("\t")[5] if ln.count("\t") >= 5 else ""
         return rows
 
 

@@ -777,7 +777,8 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
 {
     static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48", "igemm_256x16", "igemm_128x32",
                                      "igemm_128x64",  "igemm_64x128", "dgemm_direct", "igemm_64x64", "igemm_64x96", "igemm_64x48",
-                                     "igemm_64x32",   "igemm_64x64",  "igemm_128x16"};
+                                     "igemm_64x32",   "igemm_64x64",  "igemm_128x16", "igemm_32x128", "igemm_32x64"};
+    static_assert(sizeof(cfgNames) / sizeof(cfgNames[0]) == kNumTileCfgs, "one label per tile configuration");
     flops = bytes = 0;
     kernel = "?";
     switch (op.kind)
@@ -877,7 +878,18 @@ extern "C" int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, 
         const char *kernel;
         double fl, by;
         op_work(op, kernel, fl, by);
-        snprintf(line, sizeof(line), "%s\t%s\t%.6f\t%.6e\t%.6e\n", op.name.c_str(), kernel, t / reps, fl, by);
+        char geom[160] = "";
+        if (op.kind == OP_IGEMM)
+        {
+            const IGemm &g = op.g;
+            const i64 M = (i64)g.B * g.P1 * g.P0;
+            const i64 tiles = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
+            snprintf(geom, sizeof(geom), "M=%lld N=%d K=%d tiles=%lld pro=%d epi=%d lin=%d stat=%d s%d", (long long)M, g.N, g.K, (long long)tiles,
+                     g.pro, g.epi, (int)(g.S1 == 1 && g.pad0 == 0 && g.seg0 == g.K), (int)(g.rowstat >= 0), op.stream);
+        }
+        else
+            snprintf(geom, sizeof(geom), "s%d", op.stream);
+        snprintf(line, sizeof(line), "%s\t%s\t%.6f\t%.6e\t%.6e\t%s\n", op.name.c_str(), kernel, t / reps, fl, by, geom);
         all += line;
         ++n;
     }

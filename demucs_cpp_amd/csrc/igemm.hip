@@ -979,6 +979,18 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(13, 4, 1, 1, 4, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(14, 4, 1, 2, 1, DMX_SMALL_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(14, 4, 1, 2, 1, DMX_SMALL_KS, PRO_GN_GELU, EPI_STATS_FACT)
+        // quarter-height siblings: cfg 15: 32x128 of 7 (same column decomposition); 16: 32x64 of 9
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(16, 2, 2, 1, 2, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
     default:
         return -1;
     }

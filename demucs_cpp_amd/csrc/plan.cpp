@@ -68,7 +68,9 @@ int half_cfg(int cfg, bool stat)
     case 0:
         return 7;
     case 7:
-        return stat ? -1 : 9;
+        return stat ? 15 : 9;
+    case 9:
+        return 16;
     case 2:
         return 10;
     case 3:
@@ -84,23 +86,36 @@ int half_cfg(int cfg, bool stat)
     }
 }
 
-// Work per CU is what counts (co-resident workgroups share one matrix pipe per SIMD): a launch of T tiles
-// keeps the chip busy for ceil(T / 256) tile-rounds of its busiest CU, efficiency T / (256 ceil(T / 256)).
-// Large batches are efficient with the big tile; one segment (M = 2688 / 1344 rows) is not: 84 tiles of
-// 128x128 for a transformer linear2 leave two thirds of the CUs idle, 336 tiles of 64x64 do not.
+// Work per CU is what counts (co-resident workgroups share one matrix pipe per SIMD). A launch of T tiles puts
+// n = ceil(T / 256) workgroups on its busiest CU; two resident workgroups hide each other's ds_read / barrier /
+// staging latencies, ONE does not (measured at one segment per call: 252 tiles of 128x128 take 1.8x as long as
+// 504 of 64x128 for the same op, decoder.1.rewrite 224 -> 126 us; the 3 qkv linears 71 -> 50 us). So the cost of
+// a tile shape is  (n == 1 ? 1.7 : n) x tile area x (1 + small-tile overhead: staging bytes per MFMA grow as the
+// tile shrinks: +3 % per halving, from forced-half runs at batch 24),
+// minimised over the chain of bit-identical half-height siblings. Large batches keep the big tile; one segment
+// (M = 2688 / 1344 rows) gets 64x64 tiles for its transformer linears.
 int refine_cfg(int cfg, i64 M, int N, bool stat)
 {
-    auto eff = [&](int c) {
+    auto cost = [&](int c, int depth) {
         const i64 T = ((M + kTileCfgs[c].BM - 1) / kTileCfgs[c].BM) * ((N + kTileCfgs[c].BN - 1) / kTileCfgs[c].BN);
-        return (double)T / (256.0 * (double)((T + 255) / 256));
+        const i64 n = (T + 255) / 256;
+        return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
     if (const char *e = getenv("DMX_FORCE_HALF")) // experiment: 1 = one halving step for every op, 2 = two
+    {
         for (int k = atoi(e); k > 0 && half_cfg(best, stat) >= 0; --k)
             best = half_cfg(best, stat);
-    for (int c = best; c >= 0 && eff(best) < 0.85; c = half_cfg(c, stat))
-        if (eff(c) > eff(best) + 1e-9)
+        return best;
+    }
+    double bestCost = cost(cfg, 0);
+    int depth = 1;
+    for (int c = half_cfg(cfg, stat); c >= 0; c = half_cfg(c, stat), ++depth)
+        if (cost(c, depth) < bestCost * 0.95) // the model is good to a few per cent: leave the default tile unless it is clear
+        {
             best = c;
+            bestCost = cost(c, depth);
+        }
     return best;
 }
 

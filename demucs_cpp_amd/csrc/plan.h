@@ -247,8 +247,12 @@ static const TileCfg kTileCfgs[] = {
     {64, 32},   // 12  of 5
     {64, 64},   // 13  of 6 (4 x 1 waves)
     {128, 16},  // 14  of 4
+    // quarter-height siblings for one or two segments per call (M = 1344 / 2688 rows: even the half-height tiles
+    // leave most CUs with a single workgroup)
+    {32, 128},  // 15  of 7 (2 x 2 waves, 1 x 4 fragments: the column decomposition of 0 and 7, row statistics identical)
+    {32, 64},   // 16  of 9
 };
-static const int kNumTileCfgs = 15;
+static const int kNumTileCfgs = 17;
 static const int kDirectCfg = 8;
 // cfg -> its half-height sibling (-1: none); stat = the op writes row statistics
 int half_cfg(int cfg, bool stat);

@@ -549,3 +549,25 @@ extern "C" int interp_combos(void *h, int *out, int cap)
         }
     return n / 5;
 }
+
+// one line per igemm op: name, tile cfg, M, N, K, number of tiles (tools: which tile a batch size gets)
+extern "C" int interp_plan_dump(void *h, char *buf, int cap)
+{
+    Interp *it = (Interp *)h;
+    std::string all;
+    char line[256];
+    for (auto &op : it->pl.ops)
+        if (op.kind == OP_IGEMM)
+        {
+            const IGemm &g = op.g;
+            const i64 M = (i64)g.B * g.P1 * g.P0;
+            const i64 tiles = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
+            snprintf(line, sizeof(line), "%s %d %lld %d %d %lld %d\n", op.name.c_str(), g.cfg, (long long)M, g.N, g.K, (long long)tiles,
+                     (int)(g.rowstat >= 0));
+            all += line;
+        }
+    if ((int)all.size() + 1 > cap)
+        return -1;
+    memcpy(buf, all.c_str(), all.size() + 1);
+    return (int)all.size();
+}

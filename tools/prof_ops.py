@@ -21,7 +21,7 @@ prof = ctx.profile(B, int(os.environ.get("REPS", "3")))
 os.makedirs("gpurun_out", exist_ok=True)
 with open(f"gpurun_out/ops_{label}.tsv", "w") as f:
     for r in prof:
-        f.write("\t".join(str(x) for x in r) + "\n")
+        f.write("\t".join(str(x) for x in r) + "\t" + ctx.profile_geometry.get(r[0], "") + "\n")
 agg = {}
 for nm, k, ms, fl, by in prof:
     d = agg.setdefault(k, [0, 0, 0, 0])
