@@ -202,6 +202,12 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     return DMX_OK;
 }
 
+// hipGraphLaunch / capture / instantiate are not safe to call from several host threads at once in this runtime
+// (observed: SIGSEGV in hip::Graph::UpdateStreams under hipGraphLaunch when the engine's device threads replay their
+// graphs concurrently - different graphs, different streams). All graph API calls of the process go through this
+// mutex; a launch only enqueues (tens of microseconds), so the device threads lose no overlap.
+static std::mutex g_graphMutex;
+
 dmx_ctx::~dmx_ctx()
 {
     if (!m)
@@ -209,8 +215,11 @@ dmx_ctx::~dmx_ctx()
     (void)hipSetDevice(m->device);
     if (stream)
         (void)hipStreamSynchronize(stream);
-    for (auto &kv : graphs)
-        (void)hipGraphExecDestroy(kv.second);
+    {
+        std::lock_guard<std::mutex> graphLock(g_graphMutex);
+        for (auto &kv : graphs)
+            (void)hipGraphExecDestroy(kv.second);
+    }
     for (hipStream_t s : {ownStream, stream2, copyStream})
         if (s)
         {
@@ -449,8 +458,11 @@ static int run_plan(dmx_ctx *c, int batch)
     {
         if (batch != c->graphBatch)
         {
-            for (auto &kv : c->graphs)
-                (void)hipGraphExecDestroy(kv.second);
+            {
+                std::lock_guard<std::mutex> graphLock(g_graphMutex);
+                for (auto &kv : c->graphs)
+                    (void)hipGraphExecDestroy(kv.second);
+            }
             c->graphs.clear();
             c->graphBatch = batch;
             c->haveLastKey = false;
@@ -462,6 +474,7 @@ static int run_plan(dmx_ctx *c, int batch)
         {
             if (c->graphs.size() >= 8)
             {
+                std::lock_guard<std::mutex> graphLock(g_graphMutex);
                 for (auto &kv : c->graphs)
                     (void)hipGraphExecDestroy(kv.second);
                 c->graphs.clear();
@@ -473,6 +486,7 @@ static int run_plan(dmx_ctx *c, int batch)
                 if (p->ops[i].signals && !c->events[i])
                     HIPCHK(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
             hipGraph_t g = nullptr;
+            std::lock_guard<std::mutex> graphLock(g_graphMutex);
             HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             const int rc = enqueue_plan(c, p, true);
             const hipError_t e = hipStreamEndCapture(c->stream, &g);
@@ -491,7 +505,10 @@ static int run_plan(dmx_ctx *c, int batch)
         c->lastKey = key, c->haveLastKey = true;
     }
     if (exec)
+    {
+        std::lock_guard<std::mutex> graphLock(g_graphMutex);
         HIPCHK(hipGraphLaunch(exec, c->stream));
+    }
     else
         DMXCHK(enqueue_plan(c, p, two));
     c->lastBatch = batch;

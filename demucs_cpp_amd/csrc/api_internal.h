@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>

@@ -10,9 +10,14 @@
 // Math: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-exact fmaf chain, 157 TF
 // peak). Each lane reads ONE ds_read_b128 per fragment = 4 consecutive k of its row and
 // feeds 4 MFMAs; MFMA c pairs k-slot h = lane>>4 with real k = 4h + c for both
-// operands, so the 16x16x4 k-slots never need a shuffle. LDS layout [kq][row ^ swz(kq)] float4:
-// every 16-lane ds_read_b128 group hits 16 distinct 16-byte slots and every 8-lane
-// ds_write_b128 group (2 rows x 4 k-quads) 8 distinct ones (conflict free both ways).
+// operands, so the 16x16x4 k-slots never need a shuffle. LDS image: row-major, a row = its 4*KS k-quads
+// (128 B at KS = 2) with the quad index XOR-swizzled, [row][kq ^ ((row / RPB) % LPR)] float4 (RPB = rows per
+// 256 B): every 16-lane ds_read_b128 group (16 rows, one k-quad) hits 16 distinct 16-byte slots of the 64
+// banks, and a staging wave writes whole rows (8 lanes = one 128-byte row, 64 lanes = 1 KB contiguous).
+// That contiguity is what the DIRECT staging needs: kernels without a prologue transform fetch their tiles
+// with global_load_lds_dwordx4 (lane l of a wave writes LDS[M0 base + 16 l]; semantics checked by
+// tools/micro/lds_dma.hip) - no staging registers, no ds_write; the swizzle moves to the GLOBAL side (a lane
+// fetches k-quad slot ^ f(row) of its row, still one full 128-byte line per 8 lanes).
 //
 // Tile = (WAVES_M*WMF*16) x (WAVES_N*WNF*16) x (16*KS), 256 threads, LDS double buffered, staging loads
 // branch-free (out-of-range chunks read a zero page; validity kept as a bit mask for the prologues).
@@ -28,6 +33,7 @@
 // Cin*L0, Cin*stride0, Cin*pad0, seg0, K, xBatchStride are multiples of 4 elements.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef DMX_SMALL_KS
 #define DMX_SMALL_KS 2
@@ -37,6 +43,12 @@
 #endif
 #ifndef DMX_BIG_KS
 #define DMX_BIG_KS 2 // experiment: 1 = 16-deep K-tiles for the 128x128 / 64x128 tiles (half the LDS: 3 workgroups per CU)
+#endif
+#ifndef DMX_IGEMM_DIRECT
+#define DMX_IGEMM_DIRECT 0 // 1: kernels without a prologue transform stage global -> LDS directly (global_load_lds_dwordx4).
+                           // Measured at batch 24 on the same box: 120.8 (direct) vs 125.2 TFLOP/s (registers) for the
+                           // 128x128 tile, 107.9 vs 112.0 for 128x96 - the LDS write happens either way, and the direct
+                           // form needs a full vmcnt(0) drain in front of the barrier. Kept for A/B builds.
 #endif
 #ifndef DMX_KS1_WAVES
 #define DMX_KS1_WAVES 1 // experiment: min waves per SIMD the KS == 1 kernels are compiled for
@@ -79,6 +91,18 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// global -> LDS load of 16 bytes per lane (global_load_lds_dwordx4): lane l writes lds_base + 16 l; lds_base is
+// wave-uniform (M0). The builtin exists in the device pass only.
+__device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+#else
+    (void)gptr;
+    (void)lds_base;
+#endif
+}
+
 // LIN: "linear layer" addressing - one contiguous run of K floats per row (S1 == 1, no padding, K a
 // multiple of the K-tile): the staging addresses of a row just advance by one K-tile per iteration, no
 // per-tile bounds checks, tap bookkeeping or pointer selects (transformer linears, 1x1 rewrites).
@@ -94,14 +118,22 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
     constexpr int BN = WAVES_N * WNF * 16;
     constexpr int LPR = 4 * KS;              // lanes per staged row: one float4 each = the row's 16*KS floats (full 128-B lines at KS=2)
     constexpr int RP = 256 / LPR;            // rows staged per pass
-    constexpr int SWM = KS == 1 ? 2 : 1;     // LDS swizzle: row ^ (k-quad * SWM), see store_tiles
+    constexpr int RPB = 16 / LPR;            // rows per 256 B of the LDS image (swizzle period)
     constexpr int AR = BM / RP;              // A rows staged per thread (row = tid/LPR + i*RP)
     constexpr int BR = (BN + RP - 1) / RP;   // B rows staged per thread
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
     static_assert(BM % RP == 0, "BM multiple of the staging pass");
+    static_assert((RP / RPB) % LPR == 0 && (16 / RPB) % LPR == 0, "swizzle term constant per lane");
+    constexpr bool DIRECT = DMX_IGEMM_DIRECT && IL && PRO == PRO_NONE; // global -> LDS without registers
+    constexpr int BRP = BR * RP;             // B rows held (>= BN: the staging passes are whole)
 
-    __shared__ float4 As[2][4 * KS][BM];
-    __shared__ float4 Bs[2][4 * KS][BN];
+    // two buffers as DISTINCT objects, selected at compile time inside the interleaved loop: the compiler
+    // can then tell a direct load into one buffer from the fragment reads of the other (no conservative
+    // vmcnt wait in front of every ds_read)
+    __shared__ float4 As0[BM][LPR], As1[BM][LPR];
+    __shared__ float4 Bs0[BRP][LPR], Bs1[BRP][LPR];
+    auto bufA = [&](int b) -> float4(*)[LPR] { return b ? As1 : As0; };
+    auto bufB = [&](int b) -> float4(*)[LPR] { return b ? Bs1 : Bs0; };
     __shared__ int4 rowinfo[BM];         // b, p1, p0, group (-1: row >= M)
     __shared__ float2 rsum[BM][WAVES_N]; // cross-wave row statistics
 
@@ -151,6 +183,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 
     // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slane`
     const int slane = tid % LPR, srow = tid / LPR;
+    const int slaneK = slane ^ ((srow / RPB) % LPR); // k-quad this lane fetches (LDS slot `slane` of its rows)
     const i64 rowLen = (i64)p.L0 * p.Cin;
     const int rowLenI = (int)rowLen;
     const float *aRow[AR]; // X + b*xBS + in1_0*rowLen + e0  (tap s1 = 0, k = 0)
@@ -221,14 +254,14 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
     // (after the MFMA block), so the loop body starts with nothing but the global loads:
     //   loads(t+1) ; MFMA(t) ; transform+ds_write(t+1) ; addresses(t+2) ; barrier
     // Out-of-range chunks point at the zero page: PRO_NONE needs no masking at all.
-    int kl = slane * 4, s1 = 0, offb = slane * 4;
+    int kl = slaneK * 4, s1 = 0, offb = slaneK * 4;
     if (p.S1 > 1)
         while (offb >= p.seg0)
         {
             offb -= p.seg0;
             ++s1;
         }
-    int tapC = 0, tapOff = slane * 4; // tap index kl / Cin and offset inside the tap
+    int tapC = 0, tapOff = slaneK * 4; // tap index kl / Cin and offset inside the tap
     if (!LIN)
         while (tapOff >= p.Cin)
         {
@@ -272,12 +305,12 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 #pragma unroll
                 for (int i = 0; i < AR; ++i)
                 {
-                    addrA[i] = aRowOk[i] ? aRow[i] + slane * 4 : p.zero;
+                    addrA[i] = aRowOk[i] ? aRow[i] + slaneK * 4 : p.zero;
                     stepA[i] = aRowOk[i] ? 16 * KS : 0;
                     maskNext |= (aRowOk[i] ? 1u : 0u) << i;
                 }
                 if (PRO == PRO_GN_GELU)
-                    addrG = p.proW + slane * 4;
+                    addrG = p.proW + slaneK * 4;
                 return;
             }
 #pragma unroll
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 #pragma unroll
                 for (int i = 0; i < BR; ++i)
                 {
-                    addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
+                    addrB[i] = bRowOk[i] ? bRow[i] + slaneK * 4 : p.zero;
                     stepB[i] = bRowOk[i] ? 16 * KS : 0;
                 }
                 return;
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 #pragma unroll
             for (int i = 0; i < BR; ++i)
             {
-                addrB[i] = bRowOk[i] ? bRow[i] + slane * 4 : p.zero;
+                addrB[i] = bRowOk[i] ? bRow[i] + slaneK * 4 : p.zero;
                 stepB[i] = bRowOk[i] ? 16 * KS : 0;
             }
         }
@@ -375,8 +408,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
         maskHeld = maskNext;
     };
     // prologue transform (+ zero fill where a transform would make padding non-zero) + LDS write.
-    // LDS image [k-quad q][row ^ q] float4: 8-lane ds_write_b128 groups (one row, 8 k-quads, or two
-    // rows x 4) and 16-lane ds_read_b128 groups (16 rows, k-quads {2j, 2j+1}) are conflict-free.
+    // LDS image [row][slot] float4, slot = k-quad ^ f(row): this lane holds k-quad slaneK = slane ^ f(row), i.e. slot `slane`.
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
@@ -402,15 +434,11 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
                 if (!ok)
                     v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4 *>(&As[buf][slane][(srow + i * RP) ^ (slane * SWM)]) = v;
+            *reinterpret_cast<f32x4 *>(&bufA(buf)[srow + i * RP][slane]) = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-        {
-            const int rl = srow + i * RP;
-            if (BN % RP == 0 || rl < BN)
-                *reinterpret_cast<f32x4 *>(&Bs[buf][slane][rl ^ (slane * SWM)]) = bReg[i];
-        }
+            *reinterpret_cast<f32x4 *>(&bufB(buf)[srow + i * RP][slane]) = bReg[i];
     };
 
     // piece-wise staging for the interleaved loop: piece 0/1 = first / second half of the A rows,
@@ -465,7 +493,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
                         if (!ok)
                             v = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    *reinterpret_cast<f32x4 *>(&As[buf][slane][(srow + i * RP) ^ (slane * SWM)]) = v;
+                    *reinterpret_cast<f32x4 *>(&bufA(buf)[srow + i * RP][slane]) = v;
                 }
         }
         else
@@ -473,11 +501,25 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 #pragma unroll
             for (int i = 0; i < BR; ++i)
                 if ((i < BH) == (piece == 2))
-                {
-                    const int rl = srow + i * RP;
-                    if (BN % RP == 0 || rl < BN)
-                        *reinterpret_cast<f32x4 *>(&Bs[buf][slane][rl ^ (slane * SWM)]) = bReg[i];
-                }
+                    *reinterpret_cast<f32x4 *>(&bufB(buf)[srow + i * RP][slane]) = bReg[i];
+        }
+    };
+    // DIRECT staging: one global_load_lds_dwordx4 per row block; the wave's 64 lanes fill the 64 / LPR rows
+    // (wave * 64 / LPR + i * RP ...) of the image, 1 KB contiguous from the wave-uniform base in M0
+    auto dload_piece = [&](int buf, int piece) {
+        if (piece < 2)
+        {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                if ((i < AH) == (piece == 0))
+                    load_to_lds_b128(addrA[i], &bufA(buf)[wave * (64 / LPR) + i * RP][0]);
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                if ((i < BH) == (piece == 2))
+                    load_to_lds_b128(addrB[i], &bufB(buf)[wave * (64 / LPR) + i * RP][0]);
         }
     };
 
@@ -489,12 +531,29 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     compute_addrs();
-    issue_loads();
-    compute_addrs();
-    store_tiles(0);
-    if (IL)
-        issue_loads(); // tile 1 stays in registers across the first iteration; the loop computes the
-                       // addresses of tile kt+2 in its first half and issues its loads in the second
+    if constexpr (DIRECT)
+    {
+        // tiles 0 and 1 go straight to their buffers; the loop requests tile kt+2 into the buffer of tile kt
+        // in the second half of iteration kt (every wave has read tile kt completely before the barrier in
+        // the middle of the iteration)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            dload_piece(0, c);
+        compute_addrs();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            dload_piece(1, c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    else
+    {
+        issue_loads();
+        compute_addrs();
+        store_tiles(0);
+        if (IL)
+            issue_loads(); // tile 1 stays in registers across the first iteration; the loop computes the
+                           // addresses of tile kt+2 in its first half and issues its loads in the second
+    }
     __syncthreads();
     int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -514,13 +573,14 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
 #endif
     if constexpr (IL)
     {
+        const int fsw = (l15 / RPB) % LPR; // swizzle term of this lane's fragment rows
         auto read_frags = [&](int buf, int ch, f32x4 *a, f32x4 *b) {
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(&As[buf][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+                a[i] = *reinterpret_cast<const f32x4 *>(&bufA(buf)[wm * (WMF * 16) + i * 16 + l15][(ch * 4 + kq) ^ fsw]);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+                b[j] = *reinterpret_cast<const f32x4 *>(&bufB(buf)[wn * (WNF * 16) + j * 16 + l15][(ch * 4 + kq) ^ fsw]);
         };
         auto mfma16 = [&](const f32x4 *a, const f32x4 *b, int c) {
 #pragma unroll
@@ -529,47 +589,63 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
                 for (int j = 0; j < WNF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(b[j], c), f4c(a[i], c), acc[i][j], 0, 0, 0);
         };
-        // ONE barrier per K-tile, in the MIDDLE of the iteration: the ds_writes of tile kt+1 all sit in the
-        // first half, every read of tile kt's LDS image too (its k-chunk 0 fragments were fetched at the end
-        // of the previous iteration, k-chunk 1 at group 1), so after the barrier tile kt+1 is complete and
-        // tile kt's buffer is free. The second half can therefore already fetch the first fragments of tile
-        // kt+1: no ds_read latency is exposed behind the barrier, and a wave waiting at the barrier sits
-        // between two MFMA groups while the co-resident workgroup keeps the matrix pipe busy.
+        // ONE barrier per K-tile, in the MIDDLE of the iteration: the ds_writes (or, DIRECT, the landing of the
+        // direct loads) of tile kt+1 all sit before it, every read of tile kt's LDS image too (its k-chunk 0
+        // fragments were fetched at the end of the previous iteration, k-chunk 1 at group 1), so after the
+        // barrier tile kt+1 is complete and tile kt's buffer is free. The second half can therefore already
+        // fetch the first fragments of tile kt+1: no ds_read latency is exposed behind the barrier, and a wave
+        // waiting at the barrier sits between two MFMA groups while the co-resident workgroup keeps the matrix
+        // pipe busy. The buffer index is a compile-time constant (two copies of the body).
         f32x4 a0[WMF], b0[WNF], a1[WMF], b1[WNF];
-        read_frags(cur, 0, a0, b0);
-        for (int kt = 0; kt < nk; ++kt)
-        {
-            // k-chunk 0 of tile kt  |  ds_write of tile kt+1 (loaded one iteration ago) and the addresses of
-            // tile kt+2, each in four pieces
+        read_frags(0, 0, a0, b0);
+        auto iteration = [&](auto curTag) {
+            constexpr int CUR = decltype(curTag)::value;
+            // k-chunk 0 of tile kt  |  ds_write of tile kt+1 (loaded one iteration ago; not DIRECT) and the
+            // addresses of tile kt+2, each in four pieces
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a0, b0, c);
-                if (!DMX_ABL_NOSTORE)
-                    store_piece(cur ^ 1, c);
+                if (!DIRECT && !DMX_ABL_NOSTORE)
+                    store_piece(CUR ^ 1, c);
                 if (!DMX_ABL_NOADDR)
                     addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
                 if (c == 1)
-                    read_frags(cur, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
+                    read_frags(CUR, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
                 if (c == 3)
                     maskHeld = maskNext; // tile kt+1 is written out: from here on the validity of tile kt+2
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // DIRECT: this wave's part of tile kt+1 must have LANDED in LDS before the barrier publishes it. The
+            // compiler tracks direct loads only against this wave's own LDS reads (and, in the generated code,
+            // not across the loop back edge), so the wait is explicit.
+            if constexpr (DIRECT)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!DMX_ABL_NOBAR)
                 __syncthreads();
-            // k-chunk 1  |  global loads of tile kt+2 into the registers just written out, the first
-            // fragments of tile kt+1
+            // k-chunk 1  |  global loads of tile kt+2 (into the registers just written out; DIRECT: into the
+            // buffer of tile kt), the first fragments of tile kt+1
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a1, b1, c);
                 if (!DMX_ABL_NOLOAD)
-                    load_piece(c);
+                {
+                    if constexpr (DIRECT)
+                        dload_piece(CUR, c);
+                    else
+                        load_piece(c);
+                }
                 if (c == 2)
-                    read_frags(cur ^ 1, 0, a0, b0);
+                    read_frags(CUR ^ 1, 0, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            cur ^= 1;
+        };
+        for (int kt = 0; kt < nk; kt += 2)
+        {
+            iteration(std::integral_constant<int, 0>{});
+            if (kt + 1 < nk)
+                iteration(std::integral_constant<int, 1>{});
         }
     }
     else
@@ -583,10 +659,10 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
             f32x4 a[WMF], b[WNF];
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(&As[cur][ch * 4 + kq][(wm * (WMF * 16) + i * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+                a[i] = *reinterpret_cast<const f32x4 *>(&bufA(cur)[wm * (WMF * 16) + i * 16 + l15][(ch * 4 + kq) ^ ((l15 / RPB) % LPR)]);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][ch * 4 + kq][(wn * (WNF * 16) + j * 16 + l15) ^ ((ch * 4 + kq) * SWM)]);
+                b[j] = *reinterpret_cast<const f32x4 *>(&bufB(cur)[wn * (WNF * 16) + j * 16 + l15][(ch * 4 + kq) ^ ((l15 / RPB) % LPR)]);
             // k sub-step outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
             // MFMA has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
