@@ -69,6 +69,18 @@ __device__ __forceinline__ float quad_lanes_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// global -> LDS load of 16 bytes per lane (global_load_lds_dwordx4): lane l writes lds_base + 16 l; lds_base is
+// wave-uniform (M0). The builtin exists in the device pass only. (Semantics: tools/micro/lds_dma.hip.)
+__device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+#else
+    (void)gptr;
+    (void)lds_base;
+#endif
+}
+
 template <int HS, int QF>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
 {
@@ -76,8 +88,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     constexpr int DF = HS / 16; // dim fragments
     constexpr int KT = 64;      // keys per tile
     constexpr int NL = (KT * DQ) / 256; // float4 loads per thread per tile (K and V each)
-    __shared__ float4 Ks[2][DQ][KT];
-    __shared__ float4 Vt[2][KT / 4][HS];
+    // K image: d_h = 64: row-major [key][dim-quad ^ (key & 15)] (a key = 256 B), filled by DIRECT global -> LDS loads
+    // (global_load_lds_dwordx4: no staging registers - the software pipeline below needs them for the scores of
+    // two tiles); d_h = 48 (rows of 192 B do not tile a wave's 1 KB): [dim-quad][key ^ 2(q&3)] through registers.
+    // Buffers are distinct objects selected at compile time (the compiler can then tell a direct load into one
+    // buffer from the fragment reads of the other).
+    constexpr bool KDIRECT = HS == 64;
+    __shared__ float4 Ks0[KDIRECT ? KT * DQ : 1], Ks1[KDIRECT ? KT * DQ : 1];
+    __shared__ float4 Kq0[KDIRECT ? 1 : DQ][KDIRECT ? 1 : KT], Kq1[KDIRECT ? 1 : DQ][KDIRECT ? 1 : KT];
+    __shared__ float4 Vt0[KT / 4][HS], Vt1[KT / 4][HS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, h4 = lane >> 4;
@@ -129,51 +148,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
     static_assert((KT * DQ) % 256 == 0, "whole staging passes");
     constexpr int NP = (KT / 4 * DQ + 255) / 256; // V passes per tile (1 for d_h = 64 and 48)
     f32x4 kreg[NL], vreg[NP][4];
-    auto load_tile = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-        {
-            const int idx = tid + i * 256;
-            const int key = idx / DQ, dq = idx - key * DQ;
-            const i64 r = min(t0 + key, p.Tk - 1);
-            kreg[i] = *reinterpret_cast<const f32x4 *>(K + r * p.ldk + 4 * dq);
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-        {
-            const int idx = tid + i * 256;
-            const int kq4 = min(idx / DQ, KT / 4 - 1), dq = idx - (idx / DQ) * DQ;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                const i64 r = min(t0 + 4 * kq4 + j, p.Tk - 1);
-                vreg[i][j] = *reinterpret_cast<const f32x4 *>(V + r * p.ldv + 4 * dq);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-        {
-            const int idx = tid + i * 256;
-            const int key = idx / DQ, dq = idx - key * DQ;
-            *reinterpret_cast<f32x4 *>(&Ks[buf][dq][key ^ (2 * (dq & 3))]) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-        {
-            const int idx = tid + i * 256;
-            const int kq4 = idx / DQ, dq = idx - kq4 * DQ;
-            if ((KT / 4 * DQ) % 256 == 0 || kq4 < KT / 4)
-            {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) // dim 4 dq + c: keys 4 kq4 .. +3
-                    *reinterpret_cast<f32x4 *>(&Vt[buf][kq4][(4 * dq + c) ^ ((dq >> 1) & 3)]) =
-                        f32x4{vreg[i][0][c], vreg[i][1][c], vreg[i][2][c], vreg[i][3][c]};
-            }
-        }
-    };
-
     f32x4 o[QF][DF];
     float mrun[QF], lrun[QF];
 #pragma unroll
@@ -188,136 +162,282 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
 
     const int nt = (p.Tk + KT - 1) / KT;
     const bool partial = (p.Tk % KT) != 0;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    int cur = 0;
-    // one key tile; MASK: the (only) tile of a Tk that is not a multiple of 64 - peeled out of the loop so that
-    // the body of the full tiles is one basic block (a uniform branch in the middle would stop the scheduler
-    // from interleaving one fragment's softmax with the other fragment's MFMAs)
-    auto tile = [&](int t, auto maskTag) {
-        constexpr bool MASK = decltype(maskTag)::value;
-        if (!DMX_ABL_ATT_NOSTAGE)
-            load_tile((t + 1) * KT); // beyond the end: clamped re-read, never stored
-        // ---- S^T = K Q^T (4 key fragments x QF query fragments), softmax per fragment, O^T += V^T P^T.
-        // (Measured alternative, kept out: per-fragment passes S_0 | S_1 + softmax_0 | PV_0 + softmax_1 | PV_1 with the
-        // K / V fragments read twice - the scheduler does interleave each softmax with the other fragment's MFMAs,
-        // but the kernel is 1 % slower than this form: 123.5 vs 124.8 TFLOP/s.)
-        f32x4 sT[QF][4];
-        auto scores = [&]() { // both fragments share the K fragments; dim step outermost, consecutive MFMAs hit different accumulators
+    // ---- software pipeline over key tiles: the scores of tile t+1 are computed (MFMA) while the softmax of tile t
+    // runs (VALU) in the same wave - the two have no data dependence, so the matrix pipe does not wait for the
+    // exp/max/sum chain. LDS therefore holds K one tile AHEAD of V:
+    //   iteration t:  reads K(t+1) [Ks[(t+1)&1]] and V(t) [Vt[t&1]];  stages K(t+2) -> Ks[t&1], V(t+1) -> Vt[(t+1)&1]
+    // (K(t) was read in iteration t-1, V(t-1) in iteration t-1: both buffers are free). The arithmetic and its
+    // order - tile by tile, deferred maximum per 16-query fragment - are unchanged.
+    // K(t0 ..) -> registers, or (KDIRECT) straight into Ks<buf>: thread (key = tid/16 + 16 i, slot = tid & 15)
+    // fetches dim-quad slot ^ (key & 15); a wave fills 4 keys = 1 KB contiguous from the wave-uniform base
+    auto load_k = [&](int t0, int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+        {
+            const int idx = tid + i * 256;
+            const int key = idx / DQ, dq = idx - key * DQ;
+            const i64 r = min(t0 + key, p.Tk - 1);
+            if constexpr (KDIRECT)
+                load_to_lds_b128(K + r * p.ldk + 4 * (dq ^ (key & 15)), &(buf ? Ks1 : Ks0)[(4 * wave + 16 * i) * DQ]);
+            else
+                kreg[i] = *reinterpret_cast<const f32x4 *>(K + r * p.ldk + 4 * dq);
+        }
+    };
+    auto load_v = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+        {
+            const int idx = tid + i * 256;
+            const int kq4 = min(idx / DQ, KT / 4 - 1), dq = idx - (idx / DQ) * DQ;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const i64 r = min(t0 + 4 * kq4 + j, p.Tk - 1);
+                vreg[i][j] = *reinterpret_cast<const f32x4 *>(V + r * p.ldv + 4 * dq);
+            }
+        }
+    };
+    auto store_k = [&](int buf) {
+        if constexpr (!KDIRECT)
+        {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+            {
+                const int idx = tid + i * 256;
+                const int key = idx / DQ, dq = idx - key * DQ;
+                *reinterpret_cast<f32x4 *>(&(buf ? Kq1 : Kq0)[dq][key ^ (2 * (dq & 3))]) = kreg[i];
+            }
+        }
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+        {
+            const int idx = tid + i * 256;
+            const int kq4 = idx / DQ, dq = idx - kq4 * DQ;
+            if ((KT / 4 * DQ) % 256 == 0 || kq4 < KT / 4)
+            {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) // dim 4 dq + c: keys 4 kq4 .. +3
+                    *reinterpret_cast<f32x4 *>(&(buf ? Vt1 : Vt0)[kq4][(4 * dq + c) ^ ((dq >> 1) & 3)]) =
+                        f32x4{vreg[i][0][c], vreg[i][1][c], vreg[i][2][c], vreg[i][3][c]};
+            }
+        }
+    };
+    // S^T = K Q^T of the tile in Ks[buf] (4 key fragments x QF query fragments); dim step outermost, consecutive
+    // MFMAs hit different accumulators
+    // (kk0 .. kk1: dim chunks of 16 - the pipelined step issues them in pieces between the parts of the softmax)
+    auto scores_part = [&](int buf, f32x4 (*sT)[4], int kk0, int kk1) {
+        if (kk0 == 0)
+        {
 #pragma unroll
             for (int f = 0; f < QF; ++f)
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
                     sT[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int kk = 0; kk < DF; ++kk)
+        for (int kk = kk0; kk < kk1; ++kk)
+        {
+            float4 kv[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
             {
-                float4 kv[4];
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-                    kv[kf] = Ks[cur][4 * kk + h4][(16 * kf + l15) ^ (2 * h4)];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                        for (int f = 0; f < QF; ++f)
-                            sT[f][kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c(kv[kf], c), a4c(qf[f][kk], c), sT[f][kf], 0, 0, 0);
+                if constexpr (KDIRECT)
+                    kv[kf] = (buf ? Ks1 : Ks0)[(16 * kf + l15) * DQ + ((4 * kk + h4) ^ l15)];
+                else
+                    kv[kf] = (buf ? Kq1 : Kq0)[4 * kk + h4][(16 * kf + l15) ^ (2 * h4)];
             }
-        };
-        // online softmax for query (f, l15); lane holds keys 16kf + 4h4 + r
-        auto softmax = [&](int f) {
-            if (DMX_ABL_ATT_NOSM)
-                return;
-            if constexpr (MASK)
-            {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t * KT + 16 * kf + 4 * h4 + r >= p.Tk)
-                            sT[f][kf][r] = -INFINITY;
-            }
-            float tmax = max3f(sT[f][0][0], sT[f][0][1], sT[f][0][2]);
-            tmax = max3f(tmax, sT[f][0][3], sT[f][1][0]);
-            float tmx2 = max3f(sT[f][1][1], sT[f][1][2], sT[f][1][3]);
-            tmx2 = max3f(tmx2, sT[f][2][0], sT[f][2][1]);
-            float tmx3 = max3f(sT[f][2][2], sT[f][2][3], sT[f][3][0]);
-            tmx3 = max3f(tmx3, sT[f][3][1], sT[f][3][2]);
-            tmax = max3f(tmax, tmx2, fmaxf(tmx3, sT[f][3][3]));
-            tmax = quad_lanes_max(tmax);
-            float mnew = mrun[f];
-            // The running maximum is raised only when some score of this 16-query fragment exceeds it by more than
-            // 2^16 (wave-uniform per fragment, hence the same decision in the 64- and the 128-query workgroup
-            // shape; always taken on the first tile, mrun = -inf). Otherwise the tile is exponentiated against the
-            // old maximum - in fp32 a common factor <= 2^16 on P and on the row sum costs no accuracy - and the
-            // rescale of O (one exp + 17 multiplies per fragment) is skipped.
-            if (__builtin_amdgcn_ballot_w64(tmax > mnew + kDeferLog2) != 0ull)
-            {
-                mnew = fmaxf(mnew, tmax);
-                const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
-                lrun[f] *= alpha;
-                mrun[f] = mnew;
-#pragma unroll
-                for (int d = 0; d < DF; ++d)
-                {
-                    o[f][d][0] *= alpha;
-                    o[f][d][1] *= alpha;
-                    o[f][d][2] *= alpha;
-                    o[f][d][3] *= alpha;
-                }
-            }
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int f = 0; f < QF; ++f)
+                        sT[f][kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c(kv[kf], c), a4c(qf[f][kk], c), sT[f][kf], 0, 0, 0);
+        }
+    };
+    // online softmax of tile t for query (f, l15); lane holds keys 16kf + 4h4 + r. MASK: the (only) tile of a Tk
+    // that is not a multiple of 64
+    float mcur[QF]; // maximum the current tile of fragment f is exponentiated against (set by softmax_pre)
+    auto softmax_pre = [&](int t, int f, f32x4 (*sT)[4], auto maskTag) {
+        constexpr bool MASK = decltype(maskTag)::value;
+        if (DMX_ABL_ATT_NOSM)
+            return;
+        if constexpr (MASK)
+        {
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                {
-                    const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: underflow to 0 is the right answer
-                    sT[f][kf][r] = pv;
-                    ps[kf] += pv;
-                }
-            lrun[f] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        };
-        // O_f^T += V^T P_f^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c] = one float4 of the V image
-        auto pvprod = [&]() {
+                    if (t * KT + 16 * kf + 4 * h4 + r >= p.Tk)
+                        sT[f][kf][r] = -INFINITY;
+        }
+        float tmax = max3f(sT[f][0][0], sT[f][0][1], sT[f][0][2]);
+        tmax = max3f(tmax, sT[f][0][3], sT[f][1][0]);
+        float tmx2 = max3f(sT[f][1][1], sT[f][1][2], sT[f][1][3]);
+        tmx2 = max3f(tmx2, sT[f][2][0], sT[f][2][1]);
+        float tmx3 = max3f(sT[f][2][2], sT[f][2][3], sT[f][3][0]);
+        tmx3 = max3f(tmx3, sT[f][3][1], sT[f][3][2]);
+        tmax = max3f(tmax, tmx2, fmaxf(tmx3, sT[f][3][3]));
+        tmax = quad_lanes_max(tmax);
+        float mnew = mrun[f];
+        // The running maximum is raised only when some score of this 16-query fragment exceeds it by more than
+        // 2^16 (wave-uniform per fragment, hence the same decision in the 64- and the 128-query workgroup
+        // shape; always taken on the first tile, mrun = -inf). Otherwise the tile is exponentiated against the
+        // old maximum - in fp32 a common factor <= 2^16 on P and on the row sum costs no accuracy - and the
+        // rescale of O (one exp + 17 multiplies per fragment) is skipped.
+        // (Measured alternative, kept out: the rescale without a branch, alpha = 1 when the maximum stays, makes the
+        // pipelined step ONE basic block so that the scheduler can spread the next tile's score MFMAs over all the
+        // exponentials - but the always-executed rescale and the longer live ranges cost more than the overlap
+        // gains: 118.3 vs 123.8 TFLOP/s for the 64-query shape, spills in the loop for the 128-query shape.)
+        if (__builtin_amdgcn_ballot_w64(tmax > mnew + kDeferLog2) != 0ull)
+        {
+            mnew = fmaxf(mnew, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
+            lrun[f] *= alpha;
+            mrun[f] = mnew;
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+            for (int d = 0; d < DF; ++d)
             {
-                f32x4 vv[DF];
+                o[f][d][0] *= alpha;
+                o[f][d][1] *= alpha;
+                o[f][d][2] *= alpha;
+                o[f][d][3] *= alpha;
+            }
+        }
+        mcur[f] = mnew;
+    };
+    auto softmax_post = [&](int f, f32x4 (*sT)[4]) {
+        if (DMX_ABL_ATT_NOSM)
+            return;
+        const float mnew = mcur[f];
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: underflow to 0 is the right answer
+                sT[f][kf][r] = pv;
+                ps[kf] += pv;
+            }
+        lrun[f] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    // O_f^T += V^T P_f^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c] = one float4 of the V image
+    auto pvprod = [&](int buf, f32x4 (*sT)[4]) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+        {
+            f32x4 vv[DF];
+#pragma unroll
+            for (int d = 0; d < DF; ++d)
+            {
+                if (DMX_ABL_ATT_NOV)
+                    vv[d] = f32x4{qf[0][d].x, qf[0][d].y, qf[0][d].z, qf[0][d].w};
+                else
+                    vv[d] = *reinterpret_cast<const f32x4 *>(&(buf ? Vt1 : Vt0)[4 * kf + h4][(16 * d + l15) ^ (((16 * d + l15) >> 3) & 3)]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int d = 0; d < DF; ++d)
-                {
-                    if (DMX_ABL_ATT_NOV)
-                        vv[d] = f32x4{qf[0][d].x, qf[0][d].y, qf[0][d].z, qf[0][d].w};
-                    else
-                        vv[d] = *reinterpret_cast<const f32x4 *>(&Vt[cur][4 * kf + h4][(16 * d + l15) ^ (((16 * d + l15) >> 3) & 3)]);
-                }
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int d = 0; d < DF; ++d)
-#pragma unroll
-                        for (int f = 0; f < QF; ++f)
-                            o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
-            }
-        };
-        scores();
+                    for (int f = 0; f < QF; ++f)
+                        o[f][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d][c], sT[f][kf][c], o[f][d], 0, 0, 0);
+        }
+    };
+
+    // prologue: K(0), V(0) -> LDS; K(1) -> LDS; S(0)
+    load_k(0, 0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    load_k(KT, 1);
+    store_k(1);
+    if constexpr (KDIRECT)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's direct loads have landed
+    __syncthreads();
+    f32x4 sA[QF][4], sB[QF][4];
+    scores_part(0, sA, 0, DF);
+    if constexpr (KDIRECT)
+        __syncthreads(); // step 0 requests K(2) straight into the buffer of K(0): every wave must have read K(0) first
+    // one pipelined step (PAR = t & 1, compile-time): softmax + PV of tile t from sCur, scores of tile t+1 into sNext
+    auto step = [&](int t, auto parTag, f32x4 (*sCur)[4], f32x4 (*sNext)[4]) {
+        constexpr int PAR = decltype(parTag)::value;
+        if (!DMX_ABL_ATT_NOSTAGE)
+        {
+            load_k((t + 2) * KT, PAR); // beyond the end: clamped re-read, never used. KDIRECT: lands in the buffer of K(t), read last in step t-1
+            if constexpr (!KDIRECT || QF == 1)
+                load_v((t + 1) * KT);
+        }
+        // The deferred-maximum test is a (wave-uniform) branch, and the scheduler interleaves only inside a basic
+        // block: the MFMAs of the next tile's scores are therefore issued in pieces, one in front of each part
+        // of the softmax, so that every block holds matrix work next to its VALU chain.
+        constexpr int H = DF / 2 > 0 ? DF / 2 : 1;
+        scores_part(PAR ^ 1, sNext, 0, H);
+        softmax_pre(t, 0, sCur, std::false_type{});
+        if constexpr (QF == 2)
+        {
+            scores_part(PAR ^ 1, sNext, H, H + (DF - H) / 2);
+            softmax_post(0, sCur);
+            softmax_pre(t, 1, sCur, std::false_type{});
+            scores_part(PAR ^ 1, sNext, H + (DF - H) / 2, DF);
+            softmax_post(1, sCur);
+        }
+        else
+        {
+            scores_part(PAR ^ 1, sNext, H, DF);
+            softmax_post(0, sCur);
+        }
+        if constexpr (KDIRECT && QF == 2)
+        {
+            // 128-query shape: the scores of two tiles, O and Q fill the register file; V(t+1) is requested only
+            // now (its 16 staging registers are not live during the phase above) and has the 128 MFMAs of the
+            // PV product to arrive
+            __builtin_amdgcn_sched_barrier(0);
+            if (!DMX_ABL_ATT_NOSTAGE)
+                load_v((t + 1) * KT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pvprod(PAR, sCur);
+        if (!DMX_ABL_ATT_NOSTAGE)
+        {
+            store_k(PAR);
+            store_v(PAR ^ 1);
+        }
+        if constexpr (KDIRECT)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto last = [&](int t, auto parTag, f32x4 (*sCur)[4]) {
+        constexpr int PAR = decltype(parTag)::value;
 #pragma unroll
         for (int f = 0; f < QF; ++f)
-            softmax(f);
-        pvprod();
-        if (!MASK && !DMX_ABL_ATT_NOSTAGE) // the masked tile is the last one: nothing left to stage
-            store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        {
+            if (partial)
+                softmax_pre(t, f, sCur, std::true_type{});
+            else
+                softmax_pre(t, f, sCur, std::false_type{});
+            softmax_post(f, sCur);
+        }
+        pvprod(PAR, sCur);
     };
-    const int nfull = partial ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t)
-        tile(t, std::false_type{});
-    if (partial)
-        tile(nt - 1, std::true_type{});
+    const std::integral_constant<int, 0> even{};
+    const std::integral_constant<int, 1> odd{};
+    int t = 0;
+    for (; t + 2 < nt; t += 2)
+    {
+        step(t, even, sA, sB);
+        step(t + 1, odd, sB, sA);
+    }
+    if (t + 1 < nt) // two tiles left: t (full) and t+1 (last)
+    {
+        step(t, even, sA, sB);
+        last(t + 1, odd, sB);
+    }
+    else // one tile left
+        last(t, even, sA);
 #pragma unroll
     for (int f = 0; f < QF; ++f)
     {
@@ -348,7 +468,8 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
     // queries); e.g. Tq = 1344 at batch 12 is 1056 big workgroups = 2.06 rounds -> 3, or 2016 small = 3.94 -> 4 x 0.6
     const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B, wg64 = (long)((a.Tq + 63) / 64) * a.H * a.B;
     const double costBig = (double)((wg128 + 511) / 512), costSmall = 0.6 * (double)((wg64 + 511) / 512);
-    const bool big = costBig <= costSmall;
+    static const int forceSmall = getenv("DMX_ATT_SMALL") ? atoi(getenv("DMX_ATT_SMALL")) : 0; // experiment: 64-query workgroups everywhere
+    const bool big = !forceSmall && costBig <= costSmall;
     if (a.hs != 64 && a.hs != 48)
         abort();
     a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);

@@ -16,6 +16,7 @@ import oracle_lib as orc
 import parity_utils as pu
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4
 SEG_FULL = 343980
 
@@ -641,3 +642,16 @@ def test_single_segment_graph_replay_is_bit_identical(dmx, tmp_models, monkeypat
         got = d_out.cpu().numpy()
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     ctx.close(); m.close()
+
+
+def test_run_to_run_determinism_stress():
+    """tools/stress_determinism.py at 12 repeats: the same batch (24, 4, 1 segments; 6-source model at 12) through the
+    hot path again and again, every output bit-identical to the first. (This is the test that caught a missing
+    barrier in front of the attention kernel's first direct K load: 1 of 25 repeats differed at batch 24, 6 of 25
+    at batch 4 - no parity test against the oracle noticed.)"""
+    import subprocess, sys
+    env = dict(os.environ, N="12")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_determinism.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 mismatching") == 4, r.stdout
