@@ -481,6 +481,21 @@ extern "C"
         it->W = it->pm.blob.data();
         return it;
     }
+    // the plan only (no arena): for tools and tests that look at the op list of big batches
+    void *interp_create_plan(const char *model_path, int64_t seg, int B)
+    {
+        auto *it = new Interp();
+        std::string err;
+        if (!load_and_pack(model_path, it->pm, err))
+        {
+            fprintf(stderr, "%s\n", err.c_str());
+            delete it;
+            return nullptr;
+        }
+        build_plan(it->pm, seg, B, it->pl);
+        it->W = nullptr;
+        return it;
+    }
     void interp_free(void *h) { delete (Interp *)h; }
     int interp_n_ops(void *h) { return (int)((Interp *)h)->pl.ops.size(); }
     double interp_arena_mb(void *h) { return (double)((Interp *)h)->pl.arenaFloats * 4 / 1e6; }

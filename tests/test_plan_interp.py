@@ -87,3 +87,48 @@ def test_two_stream_waits_cover_every_hazard(ns, interp, tmp_models):
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     assert np.array_equal(outs[0], outs[1])
     assert np.array_equal(outs[0], outs[2])
+
+
+TILES = {0: (128, 128), 1: (64, 64), 2: (128, 96), 3: (128, 48), 4: (256, 16), 5: (128, 32), 6: (128, 64), 7: (64, 128), 8: (16, 256),
+         9: (64, 64), 10: (64, 96), 11: (64, 48), 12: (64, 32), 13: (64, 64), 14: (128, 16), 15: (32, 128), 16: (32, 64)}
+# cfg -> family (column decomposition: waves x fragments along N); siblings of a family give identical bits,
+# the families with row statistics never cross (plan.h)
+FAMILY = {0: "2x4", 7: "2x4", 15: "2x4", 9: "2x2", 16: "2x2", 2: "1x6", 10: "1x6", 3: "1x3", 11: "1x3", 5: "1x2", 12: "1x2",
+          6: "1x4", 13: "1x4", 4: "1x1", 14: "1x1", 8: "direct", 1: "2x2o"}
+
+
+@pytest.mark.parametrize("ns", [4, 6])
+def test_tile_choice_keeps_the_column_tiling_at_every_batch_size(ns, interp, tmp_models):
+    """refine_cfg picks a tile per launch from the actual row count (cost model, half- and quarter-height siblings).
+    What makes that safe: an output element is the same k-ordered fmaf chain in every tile shape; for the ops that
+    also write row statistics, the COLUMN extent of the tile (hence NB, the layout of the partials and their summation
+    order) and the column decomposition are the same at every batch size; and the choice only ever shrinks the tile,
+    and only for launches that would not fill the chip a few times over."""
+    interp.interp_plan_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    interp.interp_create_plan.restype = ctypes.c_void_p
+    interp.interp_create_plan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]
+    plans = {}
+    for b in (1, 2, 3, 4, 12, 24):
+        h = interp.interp_create_plan(tmp_models[ns].encode(), 343980, b)
+        buf = ctypes.create_string_buffer(1 << 18)
+        assert interp.interp_plan_dump(h, buf, 1 << 18) > 0
+        interp.interp_free(h)
+        plans[b] = [ln.split() for ln in buf.value.decode().splitlines()]
+    ref = plans[24]
+    shrunk = 0
+    for b, ops in plans.items():
+        assert [o[0] for o in ops] == [o[0] for o in ref]
+        for o, r in zip(ops, ref):
+            name, cfg, M, N, K, tiles, stat = o[0], int(o[1]), int(o[2]), int(o[3]), int(o[4]), int(o[5]), int(o[6])
+            rcfg = int(r[1])
+            if stat:  # row statistics: same BN (hence NB and the layout of the partials) and same column decomposition
+                assert TILES[cfg][1] == TILES[rcfg][1], (name, b, cfg, rcfg)
+                assert FAMILY[cfg] == FAMILY[rcfg], (name, b, cfg, rcfg)
+            assert TILES[cfg][0] <= TILES[rcfg][0]  # fewer rows in flight never get the bigger tile
+            bm, bn = TILES[cfg]
+            assert tiles == -(-M // bm) * -(-N // bn) or cfg == 8
+            if TILES[cfg][0] < TILES[rcfg][0]:
+                shrunk += 1
+                big = -(-M // TILES[rcfg][0]) * -(-N // TILES[rcfg][1])
+                assert big <= 3 * 512, (name, b, big)  # only launches that would not fill the chip a few times over
+    assert shrunk > 20  # one and two segments per call do use the small tiles
