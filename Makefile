@@ -6,7 +6,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB := demucs_cpp_amd/lib/libdemucs_hip.so
 OBJS := $(addprefix build/,igemm.o dgemm.o fft.o misc.o attention.o api.o engine.o plan.o model_pack.o)
 
-all: $(LIB) cli oracle interp harness
+all: $(LIB) cli oracle interp harness micro
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/plan.h
 	@mkdir -p build
@@ -38,10 +38,16 @@ tests/_build/shim_harness_eigen: tests/shim_harness.cpp $(LIB) demucs_cpp_amd/ho
 	@mkdir -p tests/_build
 	g++ -O2 -std=c++17 -DDEMUCSCPP_HIP_WITH_EIGEN -Itests/eigen_stub -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../../demucs_cpp_amd/lib'
 
+# hardware-semantics checks the kernels rely on (run by the GPU tests)
+micro: tests/_build/lds_dma
+tests/_build/lds_dma: tools/micro/lds_dma.hip
+	@mkdir -p tests/_build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -o $@ $<
+
 clean:
 	rm -rf build $(LIB) tests/_build cli/*.main
 	$(MAKE) -C oracle clean
-.PHONY: all cli oracle interp harness clean
+.PHONY: all cli oracle interp harness micro clean
 
 # experiment builds: make variant NAME=timing FLAGS="-DDMX_TIMING -DDMX_PIN_LOADS=1"
 variant:

@@ -655,3 +655,15 @@ def test_run_to_run_determinism_stress():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("0 mismatching") == 4, r.stdout
+
+
+def test_global_load_lds_semantics():
+    """The attention kernel stages K with global_load_lds_dwordx4 (direct global -> LDS): lane l of a wave must write
+    LDS[M0 base + 16 l .. +16) with the 16 bytes at ITS global address. tools/micro/lds_dma.hip checks exactly that
+    on the device the tests run on."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_build", "lds_dma")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "micro"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "as expected" in r.stdout, r.stdout + r.stderr
