@@ -20,7 +20,8 @@ int main(int argc, const char **argv)
     std::cout << "demucs_ft.cpp Main driver program (MI355X HIP path)" << std::endl;
     std::string model_dir = argv[1], wav_file = argv[2], out_dir = argv[3];
     StereoMatrix audio;
-    if (!wavio::load_audio_file(wav_file, audio))
+    int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
         exit(1);
     // One bag engine instead of four demucs_model objects: the (model, segment) items of all four models are
     // dealt over the devices of DMX_DEVICES together (csrc/engine.cpp); each model still draws its own shift
@@ -70,7 +71,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * k)] = t(i, 0, k);
             wave[(size_t)(2 * k + 1)] = t(i, 1, k);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string()))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
             exit(1);
     }
     return 0;

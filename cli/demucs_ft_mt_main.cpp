@@ -31,7 +31,8 @@ int main(int argc, const char **argv)
         exit(1);
     }
     StereoMatrix audio;
-    if (!wavio::load_audio_file(wav_file, audio))
+    int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
         exit(1);
     std::array<demucs_model, 4> models;
     static const char *keys[4] = {"htdemucs_ft_drums", "htdemucs_ft_bass", "htdemucs_ft_other", "htdemucs_ft_vocals"};
@@ -73,7 +74,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * k)] = t(i, 0, k);
             wave[(size_t)(2 * k + 1)] = t(i, 1, k);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string()))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
             exit(1);
     }
     return 0;

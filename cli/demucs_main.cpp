@@ -20,7 +20,8 @@ int main(int argc, const char **argv)
     std::cout << "demucs.cpp Main driver program (MI355X HIP path)" << std::endl;
     std::string model_file = argv[1], wav_file = argv[2], out_dir = argv[3];
     StereoMatrix audio;
-    if (!wavio::load_audio_file(wav_file, audio))
+    int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
         exit(1);
     demucs_model model;
     auto ret = load_demucs_model(model_file, &model);
@@ -50,7 +51,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * i)] = out(target, 0, i);
             wave[(size_t)(2 * i + 1)] = out(target, 1, i);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string()))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
         {
             std::cerr << "Error writing " << p_target << std::endl;
             exit(1);

@@ -3,10 +3,14 @@
 // skips unknown chunks (e.g. the LIST chunk of test/data/gspi_stereo*.wav), 44.1 kHz
 // mono (duplicated to both channels, demucs.cpp:56-64) or stereo only; writes stereo
 // float32 like the reference (PCM_FLT, demucs.cpp:100-102).
+// Other sample rates are rejected with the reference's message (demucs.cpp:30-36) unless DMX_RESAMPLE=1 is set:
+// then the track is converted to 44.1 kHz on the GPU (dmx_resample) and the stems are
+// converted back and written at the file's own rate.
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -16,7 +20,15 @@
 
 namespace wavio
 {
-inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix &out)
+inline int resample_device()
+{
+    const char *d = getenv("DMX_DEVICE");
+    return d ? atoi(d) : 0;
+}
+
+// native_rate (optional): receives the file's sample rate; a rate other than 44.1 kHz is accepted only when the
+// caller passes it AND the environment says DMX_RESAMPLE=1
+inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix &out, int *native_rate = nullptr)
 {
     FILE *f = fopen(filename.c_str(), "rb");
     if (!f)
@@ -73,12 +85,16 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         std::cerr << "[ERROR] malformed wav: " << filename << std::endl;
         return false;
     }
-    if ((int)rate != demucscpp::SUPPORTED_SAMPLE_RATE)
+    const char *rs = getenv("DMX_RESAMPLE");
+    const bool convert = (int)rate != demucscpp::SUPPORTED_SAMPLE_RATE && native_rate && rs && atoi(rs) == 1 && rate > 0;
+    if ((int)rate != demucscpp::SUPPORTED_SAMPLE_RATE && !convert)
     {
         std::cerr << "[ERROR] demucs.cpp only supports the following sample rate (Hz): " << demucscpp::SUPPORTED_SAMPLE_RATE
                   << std::endl; // cli-apps/demucs.cpp:30-36
         return false;
     }
+    if (native_rate)
+        *native_rate = (int)rate;
     if (nch != 1 && nch != 2)
     {
         std::cerr << "[ERROR] demucs.cpp only supports mono and stereo audio" << std::endl; // :42-48
@@ -129,16 +145,44 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         out(0, (int64_t)i) = l;
         out(1, (int64_t)i) = r;
     }
+    if (convert)
+    {
+        const int64_t n441 = dmx_resample_length((int64_t)N, (int)rate, demucscpp::SUPPORTED_SAMPLE_RATE);
+        demucscpp::StereoMatrix conv(n441);
+        if (dmx_resample(resample_device(), out.data.data(), (int64_t)N, 2, 1, (int)rate, demucscpp::SUPPORTED_SAMPLE_RATE, conv.data.data()) != DMX_OK)
+        {
+            std::cerr << "[ERROR] sample-rate conversion failed: " << dmx_last_error() << std::endl;
+            return false;
+        }
+        std::cout << "Converted " << rate << " Hz -> " << demucscpp::SUPPORTED_SAMPLE_RATE << " Hz on the GPU: " << n441 << " samples" << std::endl;
+        out = std::move(conv);
+    }
     return true;
 }
 
-// stereo float32 WAV; `interleaved` = 2*N floats
-inline bool write_audio_file(const float *interleaved, int64_t N, const std::string &filename)
+// stereo float32 WAV; `interleaved` = 2*N floats at 44.1 kHz. out_rate != 44100 (a track that was converted on the way
+// in): the stem is converted to that rate on the GPU first.
+inline bool write_audio_file(const float *interleaved, int64_t N, const std::string &filename, int out_rate = 44100)
 {
+    std::vector<float> conv;
+    if (out_rate != demucscpp::SUPPORTED_SAMPLE_RATE)
+    {
+        const int64_t n2 = dmx_resample_length(N, demucscpp::SUPPORTED_SAMPLE_RATE, out_rate);
+        if (n2 < 0)
+            return false;
+        conv.resize((size_t)(2 * n2));
+        if (dmx_resample(resample_device(), interleaved, N, 2, 1, demucscpp::SUPPORTED_SAMPLE_RATE, out_rate, conv.data()) != DMX_OK)
+        {
+            std::cerr << "[ERROR] sample-rate conversion failed: " << dmx_last_error() << std::endl;
+            return false;
+        }
+        interleaved = conv.data();
+        N = n2;
+    }
     FILE *f = fopen(filename.c_str(), "wb");
     if (!f)
         return false;
-    const uint32_t dataBytes = (uint32_t)(N * 2 * 4), rate = 44100, byteRate = rate * 8, fmtLen = 16;
+    const uint32_t dataBytes = (uint32_t)(N * 2 * 4), rate = (uint32_t)out_rate, byteRate = rate * 8, fmtLen = 16;
     const uint32_t riffLen = 4 + (8 + fmtLen) + (8 + dataBytes);
     const uint16_t tag = 3, nch = 2, align = 8, bits = 32;
     fwrite("RIFF", 1, 4, f);

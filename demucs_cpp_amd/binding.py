@@ -30,6 +30,7 @@ EXPORTS = [
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
+    "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
     "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
@@ -238,6 +239,40 @@ class Context:
             rows.append((nm, k, float(ms), float(fl), float(by)))
             self.profile_geometry[nm] = ln.split("\t")[5] if ln.count("\t") >= 5 else ""
         return rows
+
+
+def resample_length(n_in: int, rate_in: int, rate_out: int) -> int:
+    L = lib()
+    L.dmx_resample_length.restype = ctypes.c_int64
+    L.dmx_resample_length.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    return L.dmx_resample_length(n_in, rate_in, rate_out)
+
+
+def resample_filter(rate_in: int, rate_out: int):
+    """(up, down, taps) of the polyphase filter of csrc/resample.hip (host function, no GPU)."""
+    L = lib()
+    L.dmx_resample_filter.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_int]
+    up, down, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _chk(L.dmx_resample_filter(rate_in, rate_out, ctypes.byref(up), ctypes.byref(down), ctypes.byref(nt), None, 0))
+    taps = np.zeros(nt.value, np.float32)
+    _chk(L.dmx_resample_filter(rate_in, rate_out, None, None, None, taps.ctypes.data, nt.value))
+    return up.value, down.value, taps
+
+
+def resample(x: np.ndarray, rate_in: int, rate_out: int, interleaved: bool = False, device: int = 0) -> np.ndarray:
+    """x (planes, n) planar or (n, planes) interleaved float32 -> the same layout at rate_out (GPU, host buffers)."""
+    L = lib()
+    L.dmx_resample.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_void_p]
+    x = np.ascontiguousarray(x, np.float32)
+    n, planes = (x.shape[0], x.shape[1]) if interleaved else (x.shape[1], x.shape[0])
+    m = resample_length(n, rate_in, rate_out)
+    if m < 0:
+        raise ValueError(f"invalid rates {rate_in} -> {rate_out}")
+    out = np.zeros((m, planes) if interleaved else (planes, m), np.float32)
+    _chk(L.dmx_resample(device, x.ctypes.data, n, planes, 1 if interleaved else 0, rate_in, rate_out, out.ctypes.data))
+    return out
 
 
 def engine_partition(n_segments, n_devices):

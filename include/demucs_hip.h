@@ -176,6 +176,24 @@ extern "C"
      * runs_out[(l*n_models + m)*2 + {0,1}] = segment range [g0, g1) of model m owned by device l */
     int dmx_engine_partition(const int *n_segments, int n_models, int n_devices, int *runs_out);
 
+    /* ---- sample-rate conversion on the GPU (the step in front of the path; the role
+     * libnyquist plays for the reference's CLIs, cli-apps/demucs.cpp:21-76). The reference itself rejects input that
+     * is not 44.1 kHz (:30-36) and so do the drop-in CLIs unless DMX_RESAMPLE=1 is set; there is no reference
+     * arithmetic to reproduce. Specification (csrc/resample.hip, restated in oracle/resample_oracle.py and pinned
+     * there against scipy.signal.resample_poly): L/M = rate_out/rate_in in lowest terms, R = max(L, M), c = 16 R,
+     * h[i] = sinc((i - c)/R) * kaiser(beta 8.6), i = 0..2c, sum(h) = L;  y[k] = sum_j x[j] h[c + k M - j L] for
+     * k < ceil(n L / M), x = 0 outside [0, n); per output one fp32 fmaf chain in ascending tap order.          */
+    int64_t dmx_resample_length(int64_t n_in, int rate_in, int rate_out); /* ceil(n_in L / M); -1: invalid argument */
+    /* the filter (pure host function, no GPU): up = L, down = M, taps h[0 .. n_taps-1] (taps may be NULL) */
+    int dmx_resample_filter(int rate_in, int rate_out, int *up, int *down, int *n_taps, float *taps, int cap);
+    /* `planes` signals of n_in samples; element (plane, j) at plane*plane_stride + j*sample_stride (floats):
+     * interleaved stereo = planes 2, strides 1 and 2; planar = strides n and 1. Device pointers on `device`,
+     * enqueued on `stream` (hipStream_t, may be NULL).                                                        */
+    int dmx_resample_device(int device, const float *d_in, int64_t n_in, int planes, int64_t in_plane_stride, int64_t in_sample_stride,
+                            int rate_in, int rate_out, float *d_out, int64_t out_plane_stride, int64_t out_sample_stride, void *stream);
+    /* host buffers; interleaved != 0: [n][planes], else [planes][n]; out holds dmx_resample_length() samples per plane */
+    int dmx_resample(int device, const float *in, int64_t n_in, int planes, int interleaved, int rate_in, int rate_out, float *out);
+
     /* ---- debug taps (layer-level parity tests, cf. the reference's print-only layer tests
      * test/test_layers.cpp:1390-2157): copies a named intermediate activation of the last
      * dmx_segment_infer* call to the host. shape[0] is the batch. Returns ndim or -1.      */
