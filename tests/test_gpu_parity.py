@@ -667,3 +667,50 @@ def test_global_load_lds_semantics():
         subprocess.check_call(["make", "-C", ROOT, "micro"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "as expected" in r.stdout, r.stdout + r.stderr
+
+
+def test_cli_shards_over_dmx_devices_and_finish_modes(dmx, tmp_models, tmp_path):
+    """The multi-GPU host path as a user reaches it: cli/demucs.cpp.main with DMX_DEVICES naming several (here:
+    logical) devices, in both finish modes, and `all`; cli/demucs_ft.cpp.main with the bag dealt over three devices.
+    Stems bit-identical to the one-device run of the same CLI (BASELINE configs[3] / [4] mechanics end to end)."""
+    import shutil
+    import subprocess
+    from wavio import read_wav, write_wav_f32
+    from demucs_cpp_amd.weights import write_synthetic_model
+    exe = os.path.join(ROOT, "cli", "demucs.cpp.main")
+    exe_ft = os.path.join(ROOT, "cli", "demucs_ft.cpp.main")
+    assert os.path.exists(exe) and os.path.exists(exe_ft), "CLIs not built"
+    n = 3 * 257985 + 4321  # 4 segments
+    audio = (0.1 * np.random.default_rng(77).standard_normal((2, n))).astype(np.float32)
+    wav = str(tmp_path / "in.wav")
+    write_wav_f32(wav, audio)
+    base = dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2")
+
+    def run(exe_, model, out, **env):
+        r = subprocess.run([exe_, model, wav, str(out)], env=dict(base, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        return r.stdout
+
+    names = ["drums", "bass", "other", "vocals", "guitar", "piano"]
+    run(exe, tmp_models[6], tmp_path / "one")
+    for tag, env in (("two", dict(DMX_DEVICES="0,0")), ("own", dict(DMX_DEVICES="0,0,0", DMX_FINISH="owner")), ("all", dict(DMX_DEVICES="all"))):
+        out = run(exe, tmp_models[6], tmp_path / tag, **env)
+        if tag != "all":
+            assert "device 1 (gpu 0) finished" in out  # the progress lines of the engine's device threads
+        for i in range(6):
+            _, a = read_wav(str(tmp_path / "one" / f"target_{i}_{names[i]}.wav"))
+            _, b = read_wav(str(tmp_path / tag / f"target_{i}_{names[i]}.wav"))
+            assert np.array_equal(a, b), (tag, i)
+    r = subprocess.run([exe, tmp_models[6], wav, str(tmp_path / "bad")], env=dict(base, DMX_DEVICES="0,7"), capture_output=True, text=True)
+    assert r.returncode == 1  # a device that does not exist: the model does not load
+    # the fine-tuned bag
+    ftdir = tmp_path / "ft"
+    ftdir.mkdir()
+    for i, nm in enumerate(["drums", "bass", "other", "vocals"]):
+        write_synthetic_model(str(ftdir / f"ggml-model-htdemucs_ft_{nm}-4s-f16.bin"), 4, 80 + i)
+    run(exe_ft, str(ftdir), tmp_path / "ft_one")
+    run(exe_ft, str(ftdir), tmp_path / "ft_three", DMX_DEVICES="0,0,0")
+    for i in range(4):
+        _, a = read_wav(str(tmp_path / "ft_one" / f"target_{i}_{names[i]}.wav"))
+        _, b = read_wav(str(tmp_path / "ft_three" / f"target_{i}_{names[i]}.wav"))
+        assert np.array_equal(a, b), ("ft", i)
