@@ -30,7 +30,10 @@ interp:
 	g++ -O2 -march=native -fopenmp -std=c++17 -fPIC -shared -o tests/_build/libcpu_interp.so tests/cpu_interp.cpp
 
 # GPU test harnesses of the C++ shim (re-entrancy; Eigen-typed overloads against tests/eigen_stub, which is NOT Eigen)
-harness: tests/_build/shim_harness tests/_build/shim_harness_eigen
+harness: tests/_build/shim_harness tests/_build/shim_harness_eigen tests/_build/wav_harness
+tests/_build/wav_harness: tests/wav_harness.cpp cli/wav.hpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp
+	@mkdir -p tests/_build
+	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -Icli -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../../demucs_cpp_amd/lib'
 tests/_build/shim_harness: tests/shim_harness.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp
 	@mkdir -p tests/_build
 	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../../demucs_cpp_amd/lib'

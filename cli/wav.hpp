@@ -1,5 +1,6 @@
 // wav.hpp — minimal RIFF/WAVE I/O for the CLI drivers (the reference uses libnyquist,
-// cli-apps/demucs.cpp:21-105; absent here). Reads PCM 16/24/32-bit and IEEE float32,
+// cli-apps/demucs.cpp:21-105; absent here). Reads PCM 8 (unsigned) / 16 / 24 / 32-bit, IEEE float32 / float64 and
+// the 8-bit G.711 companded encodings (A-law, mu-law; decode per ITU-T G.711, checked against Python's audioop),
 // skips unknown chunks (e.g. the LIST chunk of test/data/gspi_stereo*.wav), 44.1 kHz
 // mono (duplicated to both channels, demucs.cpp:56-64) or stereo only; writes stereo
 // float32 like the reference (PCM_FLT, demucs.cpp:100-102).
@@ -101,7 +102,8 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         return false;
     }
     // validate the encoding BEFORE bits / 8 is used as a divisor (a 4-bit ADPCM file must not die with SIGFPE)
-    if (!((tag == 3 && bits == 32) || (tag == 1 && (bits == 16 || bits == 24 || bits == 32))))
+    if (!((tag == 3 && (bits == 32 || bits == 64)) || (tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) ||
+          ((tag == 6 || tag == 7) && bits == 8)))
     {
         std::cerr << "[ERROR] unsupported wav encoding (tag " << tag << ", " << bits << " bits)" << std::endl;
         return false;
@@ -116,6 +118,29 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
             float v;
             memcpy(&v, p, 4);
             return v;
+        }
+        if (tag == 3 && bits == 64)
+        {
+            double v;
+            memcpy(&v, p, 8);
+            return (float)v;
+        }
+        if (tag == 1 && bits == 8)
+            return ((float)p[0] - 128.0f) / 128.0f; // 8-bit PCM is unsigned
+        if (tag == 7) // mu-law (G.711): sign, 3-bit exponent, 4-bit mantissa of the complemented byte, bias 0x84
+        {
+            const uint8_t u = (uint8_t)~p[0];
+            int t = (((u & 0x0F) << 3) + 0x84) << ((u & 0x70) >> 4);
+            t -= 0x84;
+            return (float)((u & 0x80) ? -t : t) / 32768.0f;
+        }
+        if (tag == 6) // A-law (G.711): byte ^ 0x55, sign bit set = positive
+        {
+            const uint8_t a = p[0] ^ 0x55;
+            const int e = (a & 0x70) >> 4;
+            int t = (a & 0x0F) << 4;
+            t = e == 0 ? t + 8 : (t + 0x108) << (e - 1);
+            return (float)((a & 0x80) ? t : -t) / 32768.0f;
         }
         if (tag == 1 && bits == 16)
         {
