@@ -1,4 +1,4 @@
-// demucs_oracle.cpp — CPU ORACLE for the HTDemucs (v4) per-segment inference hot path.
+// demucs_oracle.cpp — CPU ORACLE for the HTDemucs (v4) and Demucs v3 (hdemucs_mmi) per-segment inference hot path.
 //
 // TEST INFRASTRUCTURE ONLY. Nothing in the product path (demucs_cpp_amd/, include/, cli/)
 // may link, import or execute this file. It is loaded by tests/, by
@@ -119,6 +119,7 @@ struct Model
 {
     int n_sources = 4; // 4 ("dmc4") or 6 ("dmc6")  -- src/model_load.cpp:79-102
     int dim = 512;     // transformer width: 512 (4s, src/model.hpp:261) / 384 (6s, :282)
+    int arch = 4;      // 4: HTDemucs v4; 3: Demucs v3 hdemucs_mmi ("dmc3", src/model_load.cpp:1335-1340)
     int n_tensors = 0;
     std::map<std::string, Tensor> w;
     const Tensor &get(const std::string &name) const
@@ -158,6 +159,12 @@ static Model *load_model(const char *path)
     {
         m->n_sources = 4;
         m->dim = 512;
+    }
+    else if (magic == 0x646d6333u)
+    {
+        m->n_sources = 4; // src/model_apply.cpp:370,389 (nb_out_sources = 4)
+        m->dim = 0;
+        m->arch = 3;
     }
     else
     {
@@ -1054,13 +1061,19 @@ static void mean_std(const float *p, int64_t n, float &mean, float &stdv)
 }
 
 // ---------------------------------------------------------------------------------
-// model_inference; src/model_inference.cpp:48-475.
-// mix (2, seg) planar -> out (S, 2, seg) planar.
+// Front and back ends shared by the v4 and v3 segment graphs (the reference repeats them
+// verbatim: src/model_inference.cpp:64-144,352-474 (v4) and :489-586,719-855 (v3)).
 // ---------------------------------------------------------------------------------
-static void model_inference(const Model &m, const float *mix, int64_t seg, float *out)
+struct SegFront
 {
-    Geo g = make_geo(seg);
-    const int S = m.n_sources;
+    Tensor x;  // (4, 2048, T) CaC spectrogram, z-normalised
+    Tensor xt; // (1, 2, seg) z-normalised mix
+    float mean = 0, std_ = 0, meant = 0, stdt = 0;
+    int nfr = 0;
+};
+static SegFront segment_front(const float *mix, int64_t seg, const Geo &g)
+{
+    SegFront o;
     // reflect_padding (symmetric, Q2); model_inference.cpp:22-46,64
     std::vector<float> padded((size_t)(2 * g.padded));
     for (int ch = 0; ch < 2; ++ch)
@@ -1078,6 +1091,7 @@ static void model_inference(const Model &m, const float *mix, int64_t seg, float
     int nfr = 0;
     stft(padded.data(), g.padded, spec, nfr);
     assert(nfr == g.nfr);
+    o.nfr = nfr;
     const int64_t NB = NFFT / 2 + 1, Fq = NB - 1, T = g.le;
     // z = spec[:, :, 2:2+le]; CaC; drop bin 2048; model_inference.cpp:75-99
     Tensor x({4, Fq, T});
@@ -1091,20 +1105,61 @@ static void model_inference(const Model &m, const float *mix, int64_t seg, float
             }
     tap("x_cac", x);
     // z-norm; model_inference.cpp:115-124
-    float mean, std_;
-    mean_std(x.data(), x.numel(), mean, std_);
+    mean_std(x.data(), x.numel(), o.mean, o.std_);
     const float epsilon = 1e-5f;
     for (auto &v : x.d)
-        v = (v - mean) / (std_ + epsilon);
+        v = (v - o.mean) / (o.std_ + epsilon);
     // time branch input + z-norm; model_inference.cpp:127-144
     Tensor xt({1, 2, seg});
     std::memcpy(xt.data(), mix, sizeof(float) * (size_t)(2 * seg));
-    float meant, stdt;
-    mean_std(xt.data(), xt.numel(), meant, stdt);
+    mean_std(xt.data(), xt.numel(), o.meant, o.stdt);
     for (auto &v : xt.d)
-        v = (v - meant) / (stdt + epsilon);
+        v = (v - o.meant) / (o.stdt + epsilon);
     tap("x_norm", x);
     tap("xt_norm", xt);
+    o.x = std::move(x);
+    o.xt = std::move(xt);
+    return o;
+}
+// xc (4S, 2048, T), xtc (1, 2S, seg) -> out (S, 2, seg): de-norm, CaC undo, pad, istft, crop, add the time
+// branch; model_inference.cpp:352-474
+static void segment_back(const SegFront &fr, const Geo &g, int S, const Tensor &xc, const Tensor &xtc, int64_t seg,
+                         float *out)
+{
+    const int64_t NB = NFFT / 2 + 1, Fq = NB - 1, T = g.le;
+    const int nfr = fr.nfr;
+    for (int s = 0; s < S; ++s)
+    {
+        std::vector<std::complex<float>> sp((size_t)(2 * NB * nfr), std::complex<float>(0, 0));
+        for (int ch = 0; ch < 2; ++ch)
+            for (int64_t f = 0; f < Fq; ++f)
+                for (int64_t t = 0; t < T; ++t)
+                {
+                    float re = fr.std_ * xc.d[(size_t)(((s * 4 + 2 * ch) * Fq + f) * T + t)] + fr.mean;
+                    float im = fr.std_ * xc.d[(size_t)(((s * 4 + 2 * ch + 1) * Fq + f) * T + t)] + fr.mean;
+                    sp[(size_t)((ch * NB + f) * nfr + t + 2)] = std::complex<float>(re, im);
+                }
+        std::vector<float> wv((size_t)(2 * g.padded));
+        istft(sp, nfr, wv.data(), g.padded);
+        for (int ch = 0; ch < 2; ++ch)
+            for (int64_t i = 0; i < seg; ++i)
+            {
+                float tb = fr.stdt * xtc.d[(size_t)((s * 2 + ch) * seg + i)] + fr.meant;
+                out[(s * 2 + ch) * seg + i] = wv[(size_t)(ch * g.padded + g.pad + i)] + tb;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// model_inference; src/model_inference.cpp:48-475.
+// mix (2, seg) planar -> out (S, 2, seg) planar.
+// ---------------------------------------------------------------------------------
+static void model_inference(const Model &m, const float *mix, int64_t seg, float *out)
+{
+    Geo g = make_geo(seg);
+    const int S = m.n_sources;
+    SegFront fr = segment_front(mix, seg, g);
+    const Tensor &x = fr.x, &xt = fr.xt;
 
     Tensor saved[4], savedt[4];
     Tensor xc = x, xtc = xt;
@@ -1187,33 +1242,466 @@ static void model_inference(const Model &m, const float *mix, int64_t seg, float
         tap("tdec_" + std::to_string(k), xtc);
     }
     // xc (4S, 2048, T), xtc (1, 2S, seg)
-    // de-norm, CaC undo, pad, istft, crop, add time branch; model_inference.cpp:352-474
-    for (int s = 0; s < S; ++s)
+    segment_back(fr, g, S, xc, xtc, seg, out);
+}
+
+// =================================================================================
+// Demucs v3 (hdemucs_mmi): namespace demucscpp_v3 of the reference.
+// Encoders 0-3 / tencoders 0-3 are the v4 ones with DConv compress 4 and no norm
+// (src/encdec.cpp:363-524 = the v4 functions above, shapes come from the weights);
+// levels 4 / 5 and the decoders are restated below.
+// =================================================================================
+
+// GroupNorm with G groups, UNBIASED variance (Q3). Restates src/layers.hpp:125-168
+// generalized_group_norm: x (D0, C, L); the statistics of group g run over ALL of dim 0, the channels
+// [g C/G, (g+1) C/G) and L - dim 0 is NOT a batch for the statistics (every v3 call site has D0 == 1
+// except decoder.1's norm2, whose D0 = 8 frequency rows belong to one sample).
+static void group_norm_g(Tensor &x, const Tensor &wt, const Tensor &bs, int G, float eps, bool fuse_gelu)
+{
+    int64_t D0 = x.shape[0], C = x.shape[1], L = x.shape[2];
+    int64_t gs = C / G;
+    for (int g = 0; g < G; ++g)
     {
-        std::vector<std::complex<float>> sp((size_t)(2 * NB * nfr), std::complex<float>(0, 0));
-        for (int ch = 0; ch < 2; ++ch)
-            for (int64_t f = 0; f < Fq; ++f)
-                for (int64_t t = 0; t < T; ++t)
+        double s = 0;
+        for (int64_t i = 0; i < D0; ++i)
+            for (int64_t c = g * gs; c < (g + 1) * gs; ++c)
+                for (int64_t l = 0; l < L; ++l)
+                    s += x.d[(size_t)((i * C + c) * L + l)];
+        const double cnt = (double)(D0 * gs * L);
+        float mean = (float)(s / cnt);
+        double ss = 0;
+        for (int64_t i = 0; i < D0; ++i)
+            for (int64_t c = g * gs; c < (g + 1) * gs; ++c)
+                for (int64_t l = 0; l < L; ++l)
                 {
-                    float re = std_ * xc.d[(size_t)(((s * 4 + 2 * ch) * Fq + f) * T + t)] + mean;
-                    float im = std_ * xc.d[(size_t)(((s * 4 + 2 * ch + 1) * Fq + f) * T + t)] + mean;
-                    sp[(size_t)((ch * NB + f) * nfr + t + 2)] = std::complex<float>(re, im);
+                    double dlt = (double)x.d[(size_t)((i * C + c) * L + l)] - (double)mean;
+                    ss += dlt * dlt;
                 }
-        std::vector<float> wv((size_t)(2 * g.padded));
-        istft(sp, nfr, wv.data(), g.padded);
-        for (int ch = 0; ch < 2; ++ch)
-            for (int64_t i = 0; i < seg; ++i)
+        float var = (float)(ss / (cnt - 1.0));
+        float den = std::sqrt(var + eps);
+        for (int64_t i = 0; i < D0; ++i)
+            for (int64_t c = g * gs; c < (g + 1) * gs; ++c)
+                for (int64_t l = 0; l < L; ++l)
+                {
+                    float &p = x.d[(size_t)((i * C + c) * L + l)];
+                    float v = (p - mean) / den;
+                    v = v * wt.d[(size_t)c] + bs.d[(size_t)c];
+                    p = fuse_gelu ? gelu(v) : v;
+                }
+    }
+}
+
+// 2-layer bidirectional LSTM, zero initial state. Restates src/lstm.cpp:68-147 (lstm_forward;
+// the state is reset to zero after every call, :37-66 and layers.cpp:935,1046).
+// in (T, In) -> (T, 2H): [forward | backward] per time step (lstm.cpp:136-143).
+// gates = W_ih x_t + b_ih + W_hh h + b_hh in that order (:96-107); rows [i | f | g | o] (:109-117);
+// c = f c + i g; h = o tanh(c) (:119-126). prefix e.g. "encoder.4.dconv.layers.0.3.lstm."
+static Tensor lstm_forward(const Model &m, const std::string &prefix, const Tensor &in, int64_t H)
+{
+    const int64_t T = in.shape[0];
+    Tensor cur = in;
+    for (int layer = 0; layer < 2; ++layer)
+    {
+        const int64_t In = cur.shape[1];
+        Tensor outl({T, 2 * H});
+#pragma omp parallel for schedule(static) num_threads(2)
+        for (int dir = 0; dir < 2; ++dir)
+        {
+            std::string sfx = "l" + std::to_string(layer) + (dir ? "_reverse" : "");
+            const Tensor &wih = m.get(prefix + "weight_ih_" + sfx); // (4H, In)
+            const Tensor &whh = m.get(prefix + "weight_hh_" + sfx); // (4H, H)
+            const Tensor &bih = m.get(prefix + "bias_ih_" + sfx);
+            const Tensor &bhh = m.get(prefix + "bias_hh_" + sfx);
+            assert(wih.shape[0] == 4 * H && wih.numel() == 4 * H * In && whh.numel() == 4 * H * H);
+            std::vector<float> h((size_t)H, 0.0f), c((size_t)H, 0.0f), gates((size_t)(4 * H));
+            for (int64_t step = 0; step < T; ++step)
             {
-                float tb = stdt * xtc.d[(size_t)((s * 2 + ch) * seg + i)] + meant;
-                out[(s * 2 + ch) * seg + i] = wv[(size_t)(ch * g.padded + g.pad + i)] + tb;
+                const int64_t t = dir == 0 ? step : T - 1 - step;
+                const float *xt = &cur.d[(size_t)(t * In)];
+                for (int64_t r = 0; r < 4 * H; ++r)
+                {
+                    float a = 0.0f;
+                    const float *w = &wih.d[(size_t)(r * In)];
+                    for (int64_t k = 0; k < In; ++k)
+                        a += w[k] * xt[k];
+                    a += bih.d[(size_t)r];
+                    float b = 0.0f;
+                    const float *u = &whh.d[(size_t)(r * H)];
+                    for (int64_t k = 0; k < H; ++k)
+                        b += u[k] * h[(size_t)k];
+                    gates[(size_t)r] = (a + b) + bhh.d[(size_t)r];
+                }
+                for (int64_t j = 0; j < H; ++j)
+                {
+                    float it = 1.0f / (1.0f + std::exp(-gates[(size_t)j]));
+                    float ft = 1.0f / (1.0f + std::exp(-gates[(size_t)(H + j)]));
+                    float gt = std::tanh(gates[(size_t)(2 * H + j)]);
+                    float ot = 1.0f / (1.0f + std::exp(-gates[(size_t)(3 * H + j)]));
+                    float ct = ft * c[(size_t)j] + it * gt;
+                    c[(size_t)j] = ct;
+                    h[(size_t)j] = ot * std::tanh(ct);
+                }
+                for (int64_t j = 0; j < H; ++j)
+                    outl.d[(size_t)(t * 2 * H + dir * H + j)] = h[(size_t)j];
+            }
+        }
+        cur = outl;
+    }
+    return cur;
+}
+
+// 1x1 conv on (C, T) -> (N, T): conv1d<.., 1, 1, 0, 1> of src/layers.cpp:560-580,701-714
+static Tensor pointwise_ct(const Tensor &x, const Tensor &w, const Tensor &b)
+{
+    int64_t Cin = x.shape[0], T = x.shape[1], N = w.shape[0];
+    assert(w.numel() == N * Cin);
+    std::vector<float> A((size_t)(T * Cin)), R((size_t)(T * N));
+    for (int64_t c = 0; c < Cin; ++c)
+        for (int64_t t = 0; t < T; ++t)
+            A[(size_t)(t * Cin + c)] = x.d[(size_t)(c * T + t)];
+    sgemm_nt(T, N, Cin, A.data(), Cin, w.data(), Cin, R.data(), N, b.data());
+    Tensor o({N, T});
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t t = 0; t < T; ++t)
+            o.d[(size_t)(n * T + t)] = R[(size_t)(t * N + n)];
+    return o;
+}
+
+// LocalState attention, in place on x (C, T). Restates src/layers.cpp:533-721 local_attention:
+// 4 heads (model.hpp:690), no frequency queries (:691), 4 decay rates (:692); the decay kernel
+// kernel(d, delta) = -(d+1) |delta| / sqrt(4) is src/model.hpp:1376-1393; dots(t, s): t = key, s = query
+// (:606-650); diagonal forced to -100 (:640-648); softmax over the KEY index t per query s (:652-679);
+// result(c, s) = sum_t w(t, s) content(c, t) (:687-707); x += proj(result) (:709-720).
+static void local_attention(const Model &m, const std::string &prefix, Tensor &x)
+{
+    const int heads = 4, ndecay = 4;
+    const int64_t C = x.shape[0], T = x.shape[1], fph = C / heads;
+    Tensor q = pointwise_ct(x, m.get(prefix + "query.weight"), m.get(prefix + "query.bias"));
+    Tensor k = pointwise_ct(x, m.get(prefix + "key.weight"), m.get(prefix + "key.bias"));
+    Tensor dq = pointwise_ct(x, m.get(prefix + "query_decay.weight"), m.get(prefix + "query_decay.bias"));
+    Tensor ct = pointwise_ct(x, m.get(prefix + "content.weight"), m.get(prefix + "content.bias"));
+    for (auto &v : dq.d)
+        v = 0.5f / (1.0f + std::exp(-v)); // sigmoid / 2, layers.cpp:597-599
+    const float sq = std::sqrt((float)fph);
+    Tensor result({C, T});
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < heads; ++h)
+    {
+        std::vector<float> dots((size_t)(T * T)), w((size_t)(T * T));
+        for (int64_t t = 0; t < T; ++t)
+            for (int64_t s2 = 0; s2 < T; ++s2)
+            {
+                float dot = 0.0f, decay = 0.0f;
+                for (int64_t c = 0; c < fph; ++c)
+                    dot += q.d[(size_t)((h * fph + c) * T + s2)] * k.d[(size_t)((h * fph + c) * T + t)];
+                float v = dot / sq;
+                const int64_t delta = std::abs(t - s2);
+                for (int n = 0; n < ndecay; ++n)
+                {
+                    // decay kernel value: -(n+1) * |delta| / sqrt(ndecay); model.hpp:1376-1393
+                    float kern = -(float)(n + 1) * (float)delta / (float)std::sqrt((double)ndecay);
+                    decay += kern * dq.d[(size_t)((h * ndecay + n) * T + s2)];
+                }
+                dots[(size_t)(t * T + s2)] = t != s2 ? v + decay : -100.0f;
+            }
+        for (int64_t s2 = 0; s2 < T; ++s2)
+        {
+            float mx = -INFINITY;
+            for (int64_t t = 0; t < T; ++t)
+                mx = std::max(mx, dots[(size_t)(t * T + s2)]);
+            float sum = 0.0f;
+            for (int64_t t = 0; t < T; ++t)
+            {
+                w[(size_t)(t * T + s2)] = std::exp(dots[(size_t)(t * T + s2)] - mx);
+                sum += w[(size_t)(t * T + s2)];
+            }
+            for (int64_t t = 0; t < T; ++t)
+                w[(size_t)(t * T + s2)] /= sum;
+        }
+        for (int64_t c = 0; c < fph; ++c)
+            for (int64_t s2 = 0; s2 < T; ++s2)
+            {
+                float a = 0.0f;
+                for (int64_t t = 0; t < T; ++t)
+                    a += w[(size_t)(t * T + s2)] * ct.d[(size_t)((h * fph + c) * T + t)];
+                result.d[(size_t)((h * fph + c) * T + s2)] = a;
             }
     }
+    Tensor pr = pointwise_ct(result, m.get(prefix + "proj.weight"), m.get(prefix + "proj.bias"));
+    for (size_t i = 0; i < x.d.size(); ++i)
+        x.d[i] += pr.d[i];
+}
+
+// DConv of levels 4 / 5: conv k3 -> GroupNorm(1)+GELU -> BiLSTM + linear + skip -> LocalState ->
+// conv 1x1 -> GroupNorm(1) -> GLU -> LayerScale -> residual, two layers (dilation 1, 2).
+// Restates src/layers.cpp:877-1113 apply_dconv_v3_encoder_4_5. y (1, C, T) in place; prefix "encoder.4|5".
+static void apply_dconv_lstm(const Model &m, Tensor &y, const std::string &prefix, const std::string &tapPrefix)
+{
+    const float eps = 1e-5f;
+    const int64_t C = y.shape[1], T = y.shape[2];
+    for (int j = 0; j < 2; ++j)
+    {
+        const int d = j == 0 ? 1 : 2;
+        std::string p = prefix + ".dconv.layers." + std::to_string(j) + ".";
+        // Conv1d(C -> C/4, k3, dilation d, padding d) (+ crop to T, Q7); layers.cpp:892-905 / 996-1017
+        Tensor h = conv1d(y, m.get(p + "0.weight"), m.get(p + "0.bias"), 1, d, d, false);
+        assert(h.shape[2] == T);
+        const int64_t H = h.shape[1];
+        group_norm1(h, m.get(p + "1.weight"), m.get(p + "1.bias"), eps, true); // :907-909 / 1019-1021
+        // (T, H) view for the LSTM; :911-918
+        Tensor ym({T, H});
+        for (int64_t c = 0; c < H; ++c)
+            for (int64_t t = 0; t < T; ++t)
+                ym.d[(size_t)(t * H + c)] = h.d[(size_t)(c * T + t)];
+        Tensor lo = lstm_forward(m, p + "3.lstm.", ym, H); // (T, 2H)
+        // linear 2H -> H, then the skip connection; :926-935
+        const Tensor &lw = m.get(p + "3.linear.weight"); // (H, 2H)
+        const Tensor &lb = m.get(p + "3.linear.bias");
+        std::vector<float> lin((size_t)(T * H));
+        sgemm_nt(T, H, 2 * H, lo.data(), 2 * H, lw.data(), 2 * H, lin.data(), H, lb.data());
+        Tensor a({H, T});
+        for (int64_t c = 0; c < H; ++c)
+            for (int64_t t = 0; t < T; ++t)
+                a.d[(size_t)(c * T + t)] = lin[(size_t)(t * H + c)] + ym.d[(size_t)(t * H + c)];
+        tap(tapPrefix + "_lstm" + std::to_string(j), a);
+        local_attention(m, p + "4.", a); // :944-958
+        tap(tapPrefix + "_attn" + std::to_string(j), a);
+        Tensor a3({1, H, T});
+        a3.d = a.d;
+        // Conv1d(C/4 -> 2C, 1x1), GroupNorm(1), GLU, LayerScale, residual; :962-989 / 1077-1112
+        Tensor u = conv1d(a3, m.get(p + "5.weight"), m.get(p + "5.bias"), 1, 0, 1, false);
+        group_norm1(u, m.get(p + "6.weight"), m.get(p + "6.bias"), eps, false);
+        Tensor g = glu_dim1(u);
+        const Tensor &sc = m.get(p + "8.scale");
+        for (int64_t c = 0; c < C; ++c)
+            for (int64_t t = 0; t < T; ++t)
+            {
+                size_t idx = (size_t)(c * T + t);
+                y.d[idx] = g.d[idx] * sc.d[(size_t)c] + y.d[idx];
+            }
+    }
+}
+
+// decoders 2-5 / tdecoders 1-4: rewrite + GLU + transposed conv (+GELU) + crop, no DConv, no norm.
+// Restates src/encdec.cpp:727-863 apply_common_decoder. k = 0..3 (decoder.{k+2} / tdecoder.{k+1}).
+static Tensor apply_common_decoder_freq(const Model &m, int k, const Tensor &x, const Tensor &skip)
+{
+    std::string p = "decoder." + std::to_string(k + 2);
+    int64_t C = x.shape[0], F = x.shape[1], T = x.shape[2];
+    Tensor y({C, F, T});
+    for (size_t i = 0; i < y.d.size(); ++i)
+        y.d[i] = x.d[i] + skip.d[i]; // encdec.cpp:736
+    Tensor r = conv2d(y, m.get(p + ".rewrite.weight"), m.get(p + ".rewrite.bias"), 1, 1, 1, 1, 1, 1, false);
+    Tensor gl({C, F, T}); // glu over dim 0; :789
+    for (int64_t c = 0; c < C; ++c)
+        for (int64_t i = 0; i < F * T; ++i)
+        {
+            float a = r.d[(size_t)(c * F * T + i)], g = r.d[(size_t)((C + c) * F * T + i)];
+            gl.d[(size_t)(c * F * T + i)] = a * (1.0f / (1.0f + std::exp(-g)));
+        }
+    Tensor z = conv_tr_h(gl, m.get(p + ".conv_tr.weight"), m.get(p + ".conv_tr.bias"), 8, 4, k < 3); // :795-842
+    int64_t Cout = z.shape[0], Hz = z.shape[1], Fo = Hz - 4;
+    Tensor out({Cout, Fo, T}); // rows [2, 2 + 4F); :853-862
+    for (int64_t c = 0; c < Cout; ++c)
+        for (int64_t f = 0; f < Fo; ++f)
+            for (int64_t t = 0; t < T; ++t)
+                out.d[(size_t)((c * Fo + f) * T + t)] = z.d[(size_t)((c * Hz + f + 2) * T + t)];
+    return out;
+}
+static Tensor apply_common_decoder_time(const Model &m, int k, const Tensor &xt, const Tensor &skip, int64_t out_len)
+{
+    std::string p = "tdecoder." + std::to_string(k + 1);
+    Tensor y(xt.shape);
+    for (size_t i = 0; i < y.d.size(); ++i)
+        y.d[i] = xt.d[i] + skip.d[i];
+    Tensor r = conv1d(y, m.get(p + ".rewrite.weight"), m.get(p + ".rewrite.bias"), 1, 1, 1, false);
+    Tensor g = glu_dim1(r);
+    int64_t C = g.shape[1], L = g.shape[2];
+    Tensor gi({C, L, 1});
+    gi.d = g.d;
+    Tensor z = conv_tr_h(gi, m.get(p + ".conv_tr.weight"), m.get(p + ".conv_tr.bias"), 8, 4, k < 3);
+    int64_t Cout = z.shape[0], Lz = z.shape[1];
+    assert(2 + out_len <= Lz);
+    Tensor out({1, Cout, out_len}); // [2, 2 + out_len); encdec.cpp:844-851
+    for (int64_t c = 0; c < Cout; ++c)
+        for (int64_t l = 0; l < out_len; ++l)
+            out.d[(size_t)(c * out_len + l)] = z.d[(size_t)(c * Lz + l + 2)];
+    return out;
+}
+
+// ---------------------------------------------------------------------------------
+// model_v3_inference; src/model_inference.cpp:477-856. mix (2, seg) planar -> out (4, 2, seg) planar.
+// ---------------------------------------------------------------------------------
+static void model_v3_inference(const Model &m, const float *mix, int64_t seg, float *out)
+{
+    Geo g = make_geo(seg);
+    const int S = 4;
+    const float eps = 1e-5f;
+    SegFront fr = segment_front(mix, seg, g);
+    const int64_t T = g.le;
+    Tensor saved[4], savedt[4];
+    Tensor xc = fr.x, xtc = fr.xt;
+    for (int i = 0; i < 4; ++i)
+    {
+        // apply_time_encoder_v3 / apply_freq_encoder_v3 (encdec.cpp:363-524) = the v4 layers: conv k8 s4 + GELU,
+        // DConv (hidden C/4 from the weights), 1x1 rewrite, GLU
+        xtc = apply_time_encoder(m, i, xtc);
+        xc = apply_freq_encoder(m, i, xc);
+        if (i == 0)
+        {
+            // freq_emb; model_inference.cpp:599-618
+            const Tensor &E = m.get("freq_emb.embedding.weight"); // (512, 48)
+            const float emb_scale = 10.0f * 0.2f;
+            int64_t C = xc.shape[0], F = xc.shape[1], TT = xc.shape[2];
+            for (int64_t c = 0; c < C; ++c)
+                for (int64_t f = 0; f < F; ++f)
+                {
+                    float e = E.d[(size_t)(f * C + c)] * emb_scale;
+                    for (int64_t t = 0; t < TT; ++t)
+                        xc.d[(size_t)((c * F + f) * TT + t)] += e;
+                }
+        }
+        saved[i] = xc;
+        savedt[i] = xtc;
+        tap("x_" + std::to_string(i), xc);
+        tap("xt_" + std::to_string(i), xtc);
+    }
+    // tencoder 4: bare Conv1d(384 -> 768, k8, s4, p2); encdec.cpp:526-537
+    Tensor xt4 = conv1d(xtc, m.get("tencoder.4.conv.weight"), m.get("tencoder.4.conv.bias"), 4, 2, 1, false);
+    assert(xt4.shape[2] == T);
+    tap("xt_4", xt4);
+    // encoder 4: Conv2d(384 -> 768, (8,1), stride (4,1), no padding) + inject + GroupNorm(4)+GELU + DConv(LSTM,
+    // LocalState) + 1x1 rewrite + GroupNorm(4) + GLU; encdec.cpp:539-581
+    Tensor x4;
+    {
+        const Tensor &w = m.get("encoder.4.conv.weight"); // (768, 384, 8)
+        Tensor w4({w.shape[0], w.shape[1], w.shape[2], 1});
+        w4.d = w.d;
+        Tensor y = conv2d(xc, w4, m.get("encoder.4.conv.bias"), 4, 1, 0, 0, 1, 1, false); // (768, 1, T)
+        assert(y.shape[1] == 1 && y.shape[2] == T);
+        Tensor yb({1, y.shape[0], T});
+        for (size_t i = 0; i < yb.d.size(); ++i)
+            yb.d[i] = y.d[i] + xt4.d[i]; // inject; :557
+        group_norm_g(yb, m.get("encoder.4.norm1.weight"), m.get("encoder.4.norm1.bias"), 4, eps, true);
+        tap("e4_in", yb);
+        apply_dconv_lstm(m, yb, "encoder.4", "e4");
+        tap("e4_dconv", yb);
+        Tensor r = conv1d(yb, m.get("encoder.4.rewrite.weight"), m.get("encoder.4.rewrite.bias"), 1, 0, 1, false);
+        group_norm_g(r, m.get("encoder.4.norm2.weight"), m.get("encoder.4.norm2.bias"), 4, eps, false);
+        x4 = glu_dim1(r); // (1, 768, T)
+    }
+    tap("x_4", x4);
+    // encoder 5 (shared): Conv1d(768 -> 1536, k4, s2, p1) + ...; encdec.cpp:583-623
+    Tensor x5;
+    {
+        Tensor y = conv1d(x4, m.get("encoder.5.conv.weight"), m.get("encoder.5.conv.bias"), 2, 1, 1, false);
+        group_norm_g(y, m.get("encoder.5.norm1.weight"), m.get("encoder.5.norm1.bias"), 4, eps, true);
+        apply_dconv_lstm(m, y, "encoder.5", "e5");
+        Tensor r = conv1d(y, m.get("encoder.5.rewrite.weight"), m.get("encoder.5.rewrite.bias"), 1, 0, 1, false);
+        group_norm_g(r, m.get("encoder.5.norm2.weight"), m.get("encoder.5.norm2.bias"), 4, eps, false);
+        x5 = glu_dim1(r); // (1, 1536, T5)
+    }
+    tap("x_5", x5);
+    // decoder 0 (shared): input = skip alone; Conv1d k3 p1 + GroupNorm(4) + GLU; ConvTranspose1d(k4, s2) +
+    // GroupNorm(4)+GELU over the full output; crop [1, 1+T); encdec.cpp:625-663
+    Tensor d0;
+    {
+        Tensor y = conv1d(x5, m.get("decoder.0.rewrite.weight"), m.get("decoder.0.rewrite.bias"), 1, 1, 1, false);
+        group_norm_g(y, m.get("decoder.0.norm1.weight"), m.get("decoder.0.norm1.bias"), 4, eps, false);
+        Tensor gl = glu_dim1(y); // (1, 1536, T5) = "pre", unused by the time branch (model_inference.cpp:677-679)
+        int64_t C = gl.shape[1], L = gl.shape[2];
+        Tensor gi({C, L, 1});
+        gi.d = gl.d;
+        Tensor z = conv_tr_h(gi, m.get("decoder.0.conv_tr.weight"), m.get("decoder.0.conv_tr.bias"), 4, 2, false);
+        int64_t Cout = z.shape[0], Lz = z.shape[1];
+        Tensor zb({1, Cout, Lz});
+        zb.d = z.d;
+        group_norm_g(zb, m.get("decoder.0.norm2.weight"), m.get("decoder.0.norm2.bias"), 4, eps, true);
+        assert(1 + T <= Lz);
+        d0 = Tensor({1, Cout, T});
+        for (int64_t c = 0; c < Cout; ++c)
+            for (int64_t t = 0; t < T; ++t)
+                d0.d[(size_t)(c * T + t)] = zb.d[(size_t)(c * Lz + t + 1)];
+    }
+    tap("d0", d0);
+    // decoder 1 (freq): (x + skip) -> Conv2d 3x3 + GroupNorm(4) + GLU = pre; ConvTranspose2d (8,1)/(4,1) +
+    // GroupNorm(4)+GELU, no crop; encdec.cpp:665-705
+    Tensor pre, d1;
+    {
+        int64_t C = d0.shape[1];
+        Tensor y({C, 1, T});
+        for (size_t i = 0; i < y.d.size(); ++i)
+            y.d[i] = d0.d[i] + x4.d[i]; // skip = saved_4; :673
+        Tensor r = conv2d(y, m.get("decoder.1.rewrite.weight"), m.get("decoder.1.rewrite.bias"), 1, 1, 1, 1, 1, 1, false);
+        Tensor rb({1, r.shape[0], T});
+        rb.d = r.d;
+        group_norm_g(rb, m.get("decoder.1.norm1.weight"), m.get("decoder.1.norm1.bias"), 4, eps, false);
+        Tensor gl = glu_dim1(rb); // (1, 768, T)
+        pre = gl;
+        Tensor gi({gl.shape[1], 1, T});
+        gi.d = gl.d;
+        Tensor z = conv_tr_h(gi, m.get("decoder.1.conv_tr.weight"), m.get("decoder.1.conv_tr.bias"), 8, 4, false); // (384, 8, T)
+        assert(z.shape[1] == 8);
+        // GroupNorm over (freq rows, group channels, T): group_norm_fused_gelu_2, layers.hpp:211-225
+        int64_t Co = z.shape[0], Fz = z.shape[1];
+        Tensor zs({Fz, Co, T});
+        for (int64_t c = 0; c < Co; ++c)
+            for (int64_t f = 0; f < Fz; ++f)
+                for (int64_t t = 0; t < T; ++t)
+                    zs.d[(size_t)((f * Co + c) * T + t)] = z.d[(size_t)((c * Fz + f) * T + t)];
+        group_norm_g(zs, m.get("decoder.1.norm2.weight"), m.get("decoder.1.norm2.bias"), 4, eps, true);
+        d1 = Tensor({Co, Fz, T});
+        for (int64_t c = 0; c < Co; ++c)
+            for (int64_t f = 0; f < Fz; ++f)
+                for (int64_t t = 0; t < T; ++t)
+                    d1.d[(size_t)((c * Fz + f) * T + t)] = zs.d[(size_t)((f * Co + c) * T + t)];
+    }
+    tap("d1", d1);
+    // tdecoder 0: ConvTranspose1d(768 -> 384, k8, s4) on pre + GroupNorm(4)+GELU, crop [2, 2+L3); encdec.cpp:707-725
+    Tensor td0;
+    {
+        int64_t C = pre.shape[1];
+        Tensor gi({C, T, 1});
+        gi.d = pre.d;
+        Tensor z = conv_tr_h(gi, m.get("tdecoder.0.conv_tr.weight"), m.get("tdecoder.0.conv_tr.bias"), 8, 4, false);
+        int64_t Cout = z.shape[0], Lz = z.shape[1];
+        Tensor zb({1, Cout, Lz});
+        zb.d = z.d;
+        group_norm_g(zb, m.get("tdecoder.0.norm2.weight"), m.get("tdecoder.0.norm2.bias"), 4, eps, true);
+        const int64_t L3 = g.Lt[4];
+        assert(2 + L3 <= Lz);
+        td0 = Tensor({1, Cout, L3});
+        for (int64_t c = 0; c < Cout; ++c)
+            for (int64_t l = 0; l < L3; ++l)
+                td0.d[(size_t)(c * L3 + l)] = zb.d[(size_t)(c * Lz + l + 2)];
+    }
+    tap("td0", td0);
+    xc = d1;
+    xtc = td0;
+    for (int k = 0; k < 4; ++k) // model_inference.cpp:685-715
+    {
+        xc = apply_common_decoder_freq(m, k, xc, saved[3 - k]);
+        xtc = apply_common_decoder_time(m, k, xtc, savedt[3 - k], g.Lt[3 - k]);
+        tap("dec_" + std::to_string(k), xc);
+        tap("tdec_" + std::to_string(k), xtc);
+    }
+    segment_back(fr, g, S, xc, xtc, seg, out);
+}
+
+// dispatch on the architecture of the loaded file
+static void segment_inference_any(const Model &m, const float *mix, int64_t seg, float *out)
+{
+    if (m.arch == 3)
+        model_v3_inference(m, mix, seg, out);
+    else
+        model_inference(m, mix, seg, out);
 }
 
 // ---------------------------------------------------------------------------------
 // demucs_inference / shift / split / segment; src/model_apply.cpp:21-288.
 // audio (2, N) planar -> out (S, 2, N) planar. shift_offset replaces rand()%22050
-// (Q4). seg normally 343980.
+// (Q4). seg normally 343980. The v3 driver (src/model_apply.cpp:290-535) is the same code
+// with nb_out_sources = 4 and model_v3_inference per segment.
 // ---------------------------------------------------------------------------------
 static void demucs_inference(const Model &m, const float *audio, int64_t N, int shift_offset,
                              int64_t seg, float *out)
@@ -1273,7 +1761,7 @@ static void demucs_inference(const Model &m, const float *audio, int64_t N, int 
         for (int ch = 0; ch < 2; ++ch)
             for (int64_t i = 0; i < chunk; ++i)
                 mixbuf[(size_t)(ch * seg + left + i)] = sh[(size_t)(ch * len + off + i)];
-        model_inference(m, mixbuf.data(), seg, tout.data());
+        segment_inference_any(m, mixbuf.data(), seg, tout.data());
         for (int s = 0; s < S; ++s)
             for (int ch = 0; ch < 2; ++ch)
                 for (int64_t k = 0; k < chunk; ++k)
@@ -1325,8 +1813,9 @@ extern "C"
     // mix (2, seg) planar -> out (S, 2, seg) planar
     void orc_segment_infer(void *m, const float *mix, int64_t seg, float *out)
     {
-        orc::model_inference(*(orc::Model *)m, mix, seg, out);
+        orc::segment_inference_any(*(orc::Model *)m, mix, seg, out);
     }
+    int orc_model_arch(void *m) { return ((orc::Model *)m)->arch; }
     // audio (2, N) planar -> out (S, 2, N) planar
     void orc_track_infer(void *m, const float *audio, int64_t N, int shift_offset, int64_t seg,
                          float *out)
@@ -1437,6 +1926,34 @@ extern "C"
         std::memcpy(bt.data(), b, sizeof(float) * bt.d.size());
         orc::Tensor o = orc::conv_tr_h(xt, wt, bt, K, s, fuse_gelu != 0);
         std::memcpy(y, o.data(), sizeof(float) * o.d.size());
+    }
+    // ---- v3 primitives ----
+    // GroupNorm with G groups over (D0, C/G, L), optional gelu, in place
+    void orc_group_norm_g(float *x, int64_t D0, int64_t C, int64_t L, const float *w, const float *b, int G, float eps,
+                          int fuse_gelu)
+    {
+        orc::Tensor xt({D0, C, L}), wt({C}), bt({C});
+        std::memcpy(xt.data(), x, sizeof(float) * xt.d.size());
+        std::memcpy(wt.data(), w, sizeof(float) * (size_t)C);
+        std::memcpy(bt.data(), b, sizeof(float) * (size_t)C);
+        orc::group_norm_g(xt, wt, bt, G, eps, fuse_gelu != 0);
+        std::memcpy(x, xt.data(), sizeof(float) * xt.d.size());
+    }
+    // 2-layer BiLSTM of the loaded v3 model: in (T, H) -> out (T, 2H); prefix "encoder.4.dconv.layers.0.3.lstm."
+    void orc_lstm(void *m, const char *prefix, const float *in, int64_t T, int64_t H, float *out)
+    {
+        orc::Tensor x({T, H});
+        std::memcpy(x.data(), in, sizeof(float) * x.d.size());
+        orc::Tensor o = orc::lstm_forward(*(orc::Model *)m, prefix, x, H);
+        std::memcpy(out, o.data(), sizeof(float) * o.d.size());
+    }
+    // LocalState attention of the loaded v3 model, in place on x (C, T); prefix "encoder.4.dconv.layers.0.4."
+    void orc_local_attention(void *m, const char *prefix, float *x, int64_t C, int64_t T)
+    {
+        orc::Tensor t({C, T});
+        std::memcpy(t.data(), x, sizeof(float) * t.d.size());
+        orc::local_attention(*(orc::Model *)m, prefix, t);
+        std::memcpy(x, t.data(), sizeof(float) * t.d.size());
     }
     void orc_sin_embedding_2d(int64_t C, int64_t H, int64_t W, float *out)
     {

@@ -49,6 +49,10 @@ def lib():
         L.orc_sin_embedding_2d.argtypes = [i64, i64, i64, f32p]
         L.orc_sin_embedding_1d.argtypes = [i64, i64, f32p]
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
+        L.orc_model_arch.argtypes = [vp]
+        L.orc_group_norm_g.argtypes = [f32p, i64, i64, i64, f32p, f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+        L.orc_lstm.argtypes = [vp, ctypes.c_char_p, f32p, i64, i64, f32p]
+        L.orc_local_attention.argtypes = [vp, ctypes.c_char_p, f32p, i64, i64]
         _lib = L
     return _lib
 
@@ -64,6 +68,7 @@ class OracleModel:
             raise RuntimeError(lib().orc_last_error().decode())
         self.n_sources = lib().orc_model_n_sources(self.h)
         self.n_tensors = lib().orc_model_n_tensors(self.h)
+        self.arch = lib().orc_model_arch(self.h)  # 4: HTDemucs, 3: Demucs v3 (hdemucs_mmi)
 
     def close(self):
         if self.h:
@@ -84,6 +89,30 @@ class OracleModel:
         out = np.zeros((self.n_sources, 2, n), np.float32)
         lib().orc_track_infer(self.h, audio.ctypes.data, n, int(shift_offset), seg, out.ctypes.data)
         return out
+
+
+    # ---- v3 primitives on this model's weights
+    def lstm(self, prefix, x):
+        """x (T, H) -> (T, 2H); prefix e.g. 'encoder.4.dconv.layers.0.3.lstm.'"""
+        x = _f32(x)
+        T, H = x.shape
+        out = np.zeros((T, 2 * H), np.float32)
+        lib().orc_lstm(self.h, prefix.encode(), x.ctypes.data, T, H, out.ctypes.data)
+        return out
+
+    def local_attention(self, prefix, x):
+        """x (C, T) -> (C, T); prefix e.g. 'encoder.4.dconv.layers.0.4.'"""
+        x = _f32(x).copy()
+        lib().orc_local_attention(self.h, prefix.encode(), x.ctypes.data, x.shape[0], x.shape[1])
+        return x
+
+
+def group_norm_g(x, w, b, G, eps=1e-5, gelu=False):
+    """x (D0, C, L): statistics per group over (D0, C/G, L) (reference generalized_group_norm)."""
+    x = _f32(x).copy()
+    w, b = _f32(w), _f32(b)
+    lib().orc_group_norm_g(x.ctypes.data, x.shape[0], x.shape[1], x.shape[2], w.ctypes.data, b.ctypes.data, int(G), eps, int(gelu))
+    return x
 
 
 def tap(name):
