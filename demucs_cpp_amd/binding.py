@@ -31,7 +31,7 @@ EXPORTS = [
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
-    "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
+    "dmx_model_arch", "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2
@@ -66,7 +66,7 @@ def lib():
         L.dmx_last_error.restype = ctypes.c_char_p
         L.dmx_model_load.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
         L.dmx_model_free.argtypes = [vp]
-        for f in ("dmx_model_n_sources", "dmx_model_n_tensors", "dmx_model_device"):
+        for f in ("dmx_model_n_sources", "dmx_model_n_tensors", "dmx_model_device", "dmx_model_arch"):
             getattr(L, f).argtypes = [vp]
         L.dmx_ctx_create.argtypes = [vp, i64, ci, ctypes.POINTER(vp)]
         L.dmx_ctx_free.argtypes = [vp]
@@ -118,6 +118,7 @@ class Model:
         _chk(lib().dmx_model_load(path.encode(), device, ctypes.byref(self.h)))
         self.n_sources = lib().dmx_model_n_sources(self.h)
         self.n_tensors = lib().dmx_model_n_tensors(self.h)
+        self.arch = lib().dmx_model_arch(self.h)  # 4: HTDemucs v4, 3: Demucs v3 (hdemucs_mmi)
         self.device = device
 
     def close(self):

@@ -117,6 +117,7 @@ extern "C" void dmx_model_free(dmx_model *m)
 extern "C" int dmx_model_n_sources(const dmx_model *m) { return m ? m->pm.n_sources : 0; }
 extern "C" int dmx_model_n_tensors(const dmx_model *m) { return m ? m->pm.n_tensors : 0; }
 extern "C" int dmx_model_device(const dmx_model *m) { return m ? m->device : -1; }
+extern "C" int dmx_model_arch(const dmx_model *m) { return m ? m->pm.arch : 0; }
 
 // alignment contract of the igemm staging loads (igemm.hip header) + kernel availability
 static bool validate_plan(const Plan &p, std::string &why)
@@ -184,6 +185,8 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     }
     HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
     HIPCHK(hipMalloc((void **)&c->dStats, sizeof(float) * 4));
+    HIPCHK(hipMalloc((void **)&c->dStatus, sizeof(unsigned)));
+    HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
     return DMX_OK;
 }
 
@@ -236,7 +239,7 @@ dmx_ctx::~dmx_ctx()
         (void)hipEventDestroy(evFork);
     if (evJoin)
         (void)hipEventDestroy(evJoin);
-    for (void *p : {(void *)dA, (void *)dPartials, (void *)dStats, (void *)bAudio.p, (void *)bTmp.p, (void *)bMix.p,
+    for (void *p : {(void *)dA, (void *)dPartials, (void *)dStats, (void *)dStatus, (void *)bAudio.p, (void *)bTmp.p, (void *)bMix.p,
                     (void *)bSegOut.p, (void *)bOut.p})
         if (p)
             (void)hipFree(p);
@@ -252,7 +255,7 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: null argument");
     if (m == c->m)
         return DMX_OK;
-    if (m->device != c->m->device || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
+    if (m->device != c->m->device || m->pm.arch != c->m->pm.arch || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
         m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
     c->m = m; // kernels of earlier calls hold the old weight pointer by value: no synchronisation needed
@@ -289,6 +292,17 @@ extern "C" int dmx_ctx_synchronize(dmx_ctx *c)
         return fail(DMX_ERR_ARG, "null ctx");
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->m->pm.arch == 3)
+    {
+        // the cooperative LSTM kernel bounds its spins and raises this word instead of hanging (v3.hip)
+        unsigned st = 0;
+        HIPCHK(hipMemcpy(&st, c->dStatus, sizeof(st), hipMemcpyDeviceToHost));
+        if (st != 0)
+        {
+            HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
+            return fail(DMX_ERR_HIP, "dmx_ctx_synchronize: a cooperative kernel timed out waiting for its partner workgroups (results invalid)");
+        }
+    }
     return DMX_OK;
 }
 
@@ -334,7 +348,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         k.epi = g.epi, k.act = g.act, k.Y = a(g.y), k.yBS = g.yBatchStride, k.ldy = g.ldy;
         k.res = a(g.res), k.scale = w(g.scale_w), k.epiStats = a(g.epiStats), k.epiW = w(g.epiW_w), k.epiB = w(g.epiB_w);
         k.rowstat = a(g.rowstat), k.NB = g.NB, k.table = w(g.table_w), k.tableScale = g.tableScale;
-        k.Lout = g.Lout, k.Cout = g.Cout;
+        k.Lout = g.Lout, k.Cout = g.Cout, k.trS = g.trS, k.trOff = g.trOff;
         k.M = (i64)g.B * g.P1 * g.P0;
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
@@ -395,6 +409,34 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
             launch_ola(OlaArgs{a(o.frames), a(o.xt), a(o.statsT), a(o.wss), a(o.out), o.B, o.T, o.S, o.seg, o.pad}, s);
         break;
     }
+    case OP_GROUP_STATS:
+    {
+        const GroupStats &g = op.gs;
+        launch_group_stats(GroupStatsArgs{a(g.x), a(g.out), g.B, g.rows, g.C, g.G, g.eps}, s);
+        break;
+    }
+    case OP_GN_ACT:
+    {
+        const GnAct &g = op.ga;
+        launch_gn_act(GnActArgs{a(g.x), a(g.y), a(g.stats), a(g.res), w(g.w_w), w(g.b_w), w(g.scale_w), g.B, g.rowsIn, g.C, g.G, g.mode,
+                                g.rowOff, g.rowsOut},
+                      s);
+        break;
+    }
+    case OP_LSTM:
+    {
+        const Lstm &l = op.lstm;
+        if (launch_lstm(LstmArgs{a(l.xproj), w(l.whh_w), a(l.out), a(l.sync), c->dStatus, l.B, l.T, l.H}, s) != 0)
+            return fail(DMX_ERR_ARG, "internal error: no LSTM kernel for op %s (H = %d)", op.name.c_str(), l.H);
+        break;
+    }
+    case OP_LOCAL_ATTN:
+    {
+        const LocalAttn &l = op.la;
+        if (launch_local_attn(LocalAttnArgs{a(l.qkvd), a(l.out), l.B, l.T, l.H, l.ld}, s) != 0)
+            return fail(DMX_ERR_ARG, "internal error: no LocalState kernel for op %s (T = %d, H = %d)", op.name.c_str(), l.T, l.H);
+        break;
+    }
     default:
         break;
     }
@@ -452,7 +494,7 @@ static int run_plan(dmx_ctx *c, int batch)
     // same call (same I/O buffers, model and batch) comes a second time in a row, the whole two-stream
     // schedule is captured into a HIP graph and replayed from then on (shapes are static).
     const bool graphable = c->graphMode == 1 && two && c->stream == c->ownStream;
-    const dmx_ctx::GraphKey key{c->extMix, c->extOut, c->m};
+    const dmx_ctx::GraphKey key{c->extMix, c->extOut, c->m->dW}; // the captured kernels hold the weight pointer by value
     hipGraphExec_t exec = nullptr;
     if (graphable)
     {
@@ -859,6 +901,34 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
             bytes = 4.0 * op.ola.B * ((double)op.ola.T * 2048 * 4 * op.ola.S + 4.0 * op.ola.seg * op.ola.S);
         }
         break;
+    case OP_GROUP_STATS:
+        kernel = "group_stats";
+        bytes = 4.0 * op.gs.B * op.gs.rows * op.gs.C; // the second pass re-reads from L2
+        break;
+    case OP_GN_ACT:
+    {
+        const GnAct &g = op.ga;
+        const double Co = g.mode == 2 ? g.C / 2 : g.C;
+        kernel = "gn_act";
+        bytes = 4.0 * g.B * ((double)g.rowsOut * g.C + (double)g.rowsOut * Co * (g.res >= 0 ? 2 : 1));
+        break;
+    }
+    case OP_LSTM:
+    {
+        const Lstm &l = op.lstm;
+        kernel = "lstm";
+        flops = 2.0 * l.B * l.T * 2.0 * 4.0 * l.H * l.H; // recurrent matmul of both directions
+        bytes = 4.0 * (l.B * (double)l.T * 10.0 * l.H + 8.0 * l.H * l.H);
+        break;
+    }
+    case OP_LOCAL_ATTN:
+    {
+        const LocalAttn &l = op.la;
+        kernel = "local_attn";
+        flops = 4.0 * l.B * (double)l.T * l.T * l.H; // scores + weighted content over 4 heads of H/4
+        bytes = 4.0 * l.B * l.T * ((double)l.ld + l.H);
+        break;
+    }
     default:
         break;
     }

@@ -75,20 +75,22 @@ struct dmx_ctx
     static const int kStatBlocks = 256;
     DevBuf bAudio, bTmp, bMix, bSegOut, bOut;
     float *dStats = nullptr;            // 4 floats
+    unsigned *dStatus = nullptr;        // device status word: raised by a kernel whose bounded spin timed out (v3.hip LSTM)
     std::vector<hipEvent_t> batchEvents; // progress reporting without host synchronisation of the stream
     // HIP graphs of the batch-1 plan (launch-bound latency path), keyed by the redirected I/O pointers
     struct GraphKey
     {
         const float *mix;
         float *out;
-        const dmx_model *m;
+        const float *dW; // device weights the captured kernels read (NOT the host dmx_model*: a freed model's address
+                         // can be reused by another model with different weights)
         bool operator<(const GraphKey &o) const
         {
             if (mix != o.mix)
                 return mix < o.mix;
             if (out != o.out)
                 return out < o.out;
-            return m < o.m;
+            return dW < o.dW;
         }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
             for (int fj = 0; fj < NF; ++fj)
             {
                 const int n = fj * 16 + 4 * h;
-                const int jj = 4 * p0 + trR[fj] - 2;
+                const int jj = p.trS * p0 + trR[fj] - p.trOff;
                 offs[fj] = (eOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)b * p.yBS + ((i64)p1 * p.Lout + jj) * p.ldy + trC[fj] : -1;
             }
 #pragma unroll

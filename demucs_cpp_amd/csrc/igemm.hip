@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
             for (int j = 0; j < WNF; ++j)
             {
                 const int n = colBase + j * 16;
-                const int jj = 4 * ri.z + trR[j] - 2;
+                const int jj = p.trS * ri.z + trR[j] - p.trOff;
                 offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j] : -1;
             }
             if (p.res)
@@ -1009,12 +1009,14 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_NONE, EPI_TRCONV)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_FACT) // Demucs v3 level 3: hidden 96 -> 98 factor columns
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_TRCONV)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_FACT)
         // cfg 2: 128x96
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(2, 4, 1, 2, 6, DMX_CFG2_KS, PRO_NONE, EPI_GLU)
@@ -1064,6 +1066,7 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(15, 2, 2, 1, 4, 2, PRO_NONE, EPI_TRCONV)
         DMX_CASE(15, 2, 2, 1, 4, 2, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(15, 2, 2, 1, 4, 2, PRO_GN_GELU, EPI_STATS_ONLY)
+        DMX_CASE(15, 2, 2, 1, 4, 2, PRO_GN_GELU, EPI_STATS_FACT)
         DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_LINEAR)
         DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(16, 2, 2, 1, 2, 2, PRO_NONE, EPI_GLU)

@@ -54,6 +54,7 @@ struct GemmArgs
     const float *table;
     float tableScale;
     int Lout, Cout;
+    int trS, trOff; // EPI_TRCONV: output position j = trS*p0 + r - trOff (plan.h)
     i64 M;
     const float *zero; // >= 16 B of zeros, 16-byte aligned: target of out-of-range staging loads
     unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
@@ -152,6 +153,40 @@ struct IstftOlaArgs
     int nch, fpc; // frame chunks per (batch, source) and frames per chunk (filled by the launcher)
 };
 void launch_istft_ola(const IstftOlaArgs &a, hipStream_t s);
+
+// ---- Demucs v3 (v3.hip; plan.h OP_GROUP_STATS / OP_GN_ACT / OP_LSTM / OP_LOCAL_ATTN)
+struct GroupStatsArgs
+{
+    const float *x;
+    float *out;
+    int B, rows, C, G;
+    float eps;
+};
+void launch_group_stats(const GroupStatsArgs &a, hipStream_t s);
+struct GnActArgs
+{
+    const float *x;
+    float *y;
+    const float *stats, *res, *w, *b, *scale;
+    int B, rowsIn, C, G, mode, rowOff, rowsOut;
+};
+void launch_gn_act(const GnActArgs &a, hipStream_t s);
+struct LstmArgs
+{
+    const float *xproj, *whh;
+    float *out;
+    void *gran;       // h exchange granules, lstm_sync_floats(B, H) floats; zeroed by the launcher
+    unsigned *status; // raised when a bounded spin timed out (checked by dmx_ctx_synchronize)
+    int B, T, H;
+};
+int launch_lstm(const LstmArgs &a, hipStream_t s); // -1: unsupported hidden size
+struct LocalAttnArgs
+{
+    const float *qkvd;
+    float *out;
+    int B, T, H, ld;
+};
+int launch_local_attn(const LocalAttnArgs &a, hipStream_t s); // -1: unsupported shape
 
 // ---- track level (model_apply.cpp:60-288) ----
 // partial (sum, sumsq) of the mono reference (mean over channels); audio interleaved [n][2]

@@ -1,10 +1,11 @@
-// model_pack.cpp — dmc4/dmc6 weight-file reader and repacking into GEMM-ready layouts.
+// model_pack.cpp — dmc4 / dmc6 / dmc3 weight-file reader and repacking into GEMM-ready layouts.
 //
 // File format (kept surface): /root/reference/src/model_load.cpp:79-147 (reader) and
 // /root/reference/scripts/convert-pth-to-ggml.py:111-140 (writer). Error behaviour
 // mirrors the reference loader: open failure, bad magic, unknown tensor name or
 // element-count mismatch => false + message (model_load.cpp:64-69,97-102,1065-1070,
 // 1096-1105). Unlike the reference we ALSO fail when a tensor is missing.
+// Demucs v3 ("dmc3", hdemucs_mmi): reader /root/reference/src/model_load.cpp:1302-2166, same container.
 //
 // Packing (done once on the host, then the blob lives in HBM):
 //   * every conv / linear weight becomes a row-major matrix Wt[Np][Kp] (Np = N rounded
@@ -17,6 +18,7 @@
 //     [W[:,co,r+4]; W[:,co,r]] (no zero stuffing, cf. src/conv.hpp:264-325).
 #include "plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -135,32 +137,107 @@ struct Packer
                     p[(i64)row * Kp + t * Cin + ci] = r.d[(size_t)(((i64)n * Cin + ci) * srcTaps + tapmap[(size_t)t])];
         }
     }
-    // transposed conv (Cin, Cout, 8) -> Wt[4*Cout][2*Cin], bias[4*Cout]
-    void conv_tr(const std::string &dstW, const std::string &dstB, const std::string &srcW, const std::string &srcB)
+    // transposed conv (Cin, Cout, kt), stride kt/2 (k8/s4, or v3's k4/s2) -> Wt[S*Cout][2*Cin], bias[S*Cout], S = kt/2:
+    // out[S q + r] = [x[q-1], x[q]] . [W[:, co, r + S]; W[:, co, r]]
+    void conv_tr(const std::string &dstW, const std::string &dstB, const std::string &srcW, const std::string &srcB, int kt = 8)
     {
         const Raw &r = get(srcW);
         const Raw &b = get(srcB);
+        const int S = kt / 2;
         int Cout = (int)b.numel();
-        int Cin = (int)(r.numel() / ((i64)Cout * 8));
-        int N = 4 * Cout, K = 2 * Cin, Kp = rup(K, 16), Np = rup(N, 16);
+        int Cin = (int)(r.numel() / ((i64)Cout * kt));
+        int N = S * Cout, K = 2 * Cin, Kp = rup(K, 16), Np = rup(N, 16);
         float *p = alloc(dstW, (i64)Np * Kp);
-        for (int rr = 0; rr < 4; ++rr)
+        for (int rr = 0; rr < S; ++rr)
             for (int co = 0; co < Cout; ++co)
                 for (int ci = 0; ci < Cin; ++ci)
                 {
                     i64 row = (i64)(rr * Cout + co) * Kp;
-                    p[row + 0 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * 8 + rr + 4)]; // x[q-1] * W[.., r+4]
-                    p[row + 1 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * 8 + rr)];     // x[q]   * W[.., r]
+                    p[row + 0 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * kt + rr + S)]; // x[q-1] * W[.., r+S]
+                    p[row + 1 * Cin + ci] = r.d[(size_t)(((i64)ci * Cout + co) * kt + rr)];     // x[q]   * W[.., r]
                 }
         float *pb = alloc(dstB, Np);
-        for (int rr = 0; rr < 4; ++rr)
+        for (int rr = 0; rr < S; ++rr)
             for (int co = 0; co < Cout; ++co)
                 pb[rr * Cout + co] = b.d[(size_t)co];
     }
 
-    void dconv(const std::string &p, int C)
+    // DConv of levels 4 / 5 of Demucs v3 (LSTM + LocalState); /root/reference/src/layers.cpp:877-1113.
+    void dconv_lstm(const std::string &p, int C)
     {
-        int C8 = C / 8, C8p = rup(C8, 4);
+        const int H = C / 4;
+        for (int j = 0; j < 2; ++j)
+        {
+            std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
+            std::string d = p + ".dconv." + std::to_string(j) + ".";
+            conv(d + "k1.Wt", s + "0.weight", H, C, {0, 1, 2}, false);
+            vec(d + "k1.b", s + "0.bias", rup(H, 16));
+            vec(d + "gn1.w", s + "1.weight", H);
+            vec(d + "gn1.b", s + "1.bias", H);
+            for (int layer = 0; layer < 2; ++layer)
+            {
+                const int In = layer == 0 ? H : 2 * H;
+                // input projection of both directions: rows dir*4H + 4*unit + gate (gate = i|f|g|o, lstm.cpp:109-117),
+                // bias = b_ih + b_hh (lstm.cpp:96-107)
+                // (alloc() may move the blob: fill local arrays, then copy)
+                std::vector<float> w((size_t)8 * H * In), bb((size_t)8 * H), u((size_t)8 * H * H);
+                for (int dir = 0; dir < 2; ++dir)
+                {
+                    std::string sfx = "l" + std::to_string(layer) + (dir ? "_reverse" : "");
+                    const Raw &wih = get(s + "3.lstm.weight_ih_" + sfx), &whh = get(s + "3.lstm.weight_hh_" + sfx);
+                    const Raw &bih = get(s + "3.lstm.bias_ih_" + sfx), &bhh = get(s + "3.lstm.bias_hh_" + sfx);
+                    for (int unit = 0; unit < H; ++unit)
+                        for (int g = 0; g < 4; ++g)
+                        {
+                            const i64 dst = (i64)dir * 4 * H + 4 * unit + g, src = (i64)g * H + unit;
+                            for (int k = 0; k < In; ++k)
+                                w[(size_t)(dst * In + k)] = wih.d[(size_t)(src * In + k)];
+                            for (int k = 0; k < H; ++k)
+                                u[(size_t)(dst * H + k)] = whh.d[(size_t)(src * H + k)];
+                            bb[(size_t)dst] = bih.d[(size_t)src] + bhh.d[(size_t)src];
+                        }
+                }
+                const std::string ln = d + "lstm" + std::to_string(layer);
+                std::copy(w.begin(), w.end(), alloc(ln + ".ih.Wt", (i64)w.size()));
+                std::copy(bb.begin(), bb.end(), alloc(ln + ".ih.b", (i64)bb.size()));
+                std::copy(u.begin(), u.end(), alloc(ln + ".hh", (i64)u.size()));
+            }
+            conv(d + "lin.Wt", s + "3.linear.weight", H, 2 * H, {0}, false);
+            vec(d + "lin.b", s + "3.linear.bias", rup(H, 16));
+            // LocalState projections as ONE GEMM: rows [query H | key H | content H | query_decay 16]
+            {
+                const int N = 3 * H + 16, Np = rup(N, 16);
+                std::vector<float> w((size_t)Np * H, 0.f), bb((size_t)Np, 0.f);
+                const char *nm[4] = {"query", "key", "content", "query_decay"};
+                int row = 0;
+                for (int q = 0; q < 4; ++q)
+                {
+                    const Raw &wq = get(s + "4." + nm[q] + ".weight"), &bq = get(s + "4." + nm[q] + ".bias");
+                    const int n = (int)bq.numel();
+                    for (int i = 0; i < n; ++i, ++row)
+                    {
+                        for (int k = 0; k < H; ++k)
+                            w[(size_t)((i64)row * H + k)] = wq.d[(size_t)((i64)i * H + k)];
+                        bb[(size_t)row] = bq.d[(size_t)i];
+                    }
+                }
+                std::copy(w.begin(), w.end(), alloc(d + "qkvd.Wt", (i64)w.size()));
+                std::copy(bb.begin(), bb.end(), alloc(d + "qkvd.b", (i64)bb.size()));
+            }
+            conv(d + "proj.Wt", s + "4.proj.weight", H, H, {0}, false);
+            vec(d + "proj.b", s + "4.proj.bias", rup(H, 16));
+            conv(d + "k2.Wt", s + "5.weight", 2 * C, H, {0}, false);
+            vec(d + "k2.b", s + "5.bias", 2 * C);
+            vec(d + "gn2.w", s + "6.weight", 2 * C);
+            vec(d + "gn2.b", s + "6.bias", 2 * C);
+            vec(d + "scale", s + "8.scale", C);
+        }
+    }
+
+    // compress: hidden width = C / compress (8: HTDemucs v4, 4: Demucs v3)
+    void dconv(const std::string &p, int C, int compress = 8)
+    {
+        int C8 = C / compress, C8p = rup(C8, 4);
         for (int j = 0; j < 2; ++j)
         {
             std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
@@ -367,6 +444,129 @@ static bool expected_shapes(int ns, std::map<std::string, i64> &exp)
     return true;
 }
 
+// Demucs v3 hdemucs_mmi: /root/reference/src/model.hpp:694-1236 (shapes), src/model_load.cpp:1388-2136 (names)
+static void expected_shapes_v3(std::map<std::string, i64> &exp)
+{
+    const int ch[4] = {48, 96, 192, 384};
+    auto dconv = [&](const std::string &p, int C) {
+        const int H = C / 4;
+        for (int j = 0; j < 2; ++j)
+        {
+            std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
+            exp[s + "0.weight"] = (i64)H * C * 3;
+            exp[s + "0.bias"] = H;
+            exp[s + "1.weight"] = H;
+            exp[s + "1.bias"] = H;
+            exp[s + "3.weight"] = (i64)2 * C * H;
+            exp[s + "3.bias"] = 2 * C;
+            exp[s + "4.weight"] = 2 * C;
+            exp[s + "4.bias"] = 2 * C;
+            exp[s + "6.scale"] = C;
+        }
+    };
+    auto dconv_lstm = [&](const std::string &p, int C) {
+        const int H = C / 4;
+        for (int j = 0; j < 2; ++j)
+        {
+            std::string s = p + ".dconv.layers." + std::to_string(j) + ".";
+            exp[s + "0.weight"] = (i64)H * C * 3;
+            exp[s + "0.bias"] = H;
+            exp[s + "1.weight"] = H;
+            exp[s + "1.bias"] = H;
+            for (int layer = 0; layer < 2; ++layer)
+                for (const char *sfx : {"", "_reverse"})
+                {
+                    std::string l = "l" + std::to_string(layer) + sfx;
+                    exp[s + "3.lstm.weight_ih_" + l] = (i64)4 * H * (layer == 0 ? H : 2 * H);
+                    exp[s + "3.lstm.weight_hh_" + l] = (i64)4 * H * H;
+                    exp[s + "3.lstm.bias_ih_" + l] = 4 * H;
+                    exp[s + "3.lstm.bias_hh_" + l] = 4 * H;
+                }
+            exp[s + "3.linear.weight"] = (i64)H * 2 * H;
+            exp[s + "3.linear.bias"] = H;
+            for (const char *nm : {"content", "query", "key", "proj"})
+            {
+                exp[s + "4." + nm + ".weight"] = (i64)H * H;
+                exp[s + "4." + nm + ".bias"] = H;
+            }
+            exp[s + "4.query_decay.weight"] = (i64)16 * H;
+            exp[s + "4.query_decay.bias"] = 16;
+            exp[s + "5.weight"] = (i64)2 * C * H;
+            exp[s + "5.bias"] = 2 * C;
+            exp[s + "6.weight"] = 2 * C;
+            exp[s + "6.bias"] = 2 * C;
+            exp[s + "8.scale"] = C;
+        }
+    };
+    for (int i = 0; i < 4; ++i)
+    {
+        int C = ch[i], cf = i == 0 ? 4 : ch[i - 1], ct = i == 0 ? 2 : ch[i - 1];
+        std::string e = "encoder." + std::to_string(i), t = "tencoder." + std::to_string(i);
+        exp[e + ".conv.weight"] = (i64)C * cf * 8;
+        exp[e + ".conv.bias"] = C;
+        exp[e + ".rewrite.weight"] = (i64)2 * C * C;
+        exp[e + ".rewrite.bias"] = 2 * C;
+        dconv(e, C);
+        exp[t + ".conv.weight"] = (i64)C * ct * 8;
+        exp[t + ".conv.bias"] = C;
+        exp[t + ".rewrite.weight"] = (i64)2 * C * C;
+        exp[t + ".rewrite.bias"] = 2 * C;
+        dconv(t, C);
+    }
+    exp["tencoder.4.conv.weight"] = (i64)768 * 384 * 8;
+    exp["tencoder.4.conv.bias"] = 768;
+    for (int i = 4; i < 6; ++i)
+    {
+        const int C = i == 4 ? 768 : 1536, cin = C / 2, kt = i == 4 ? 8 : 4;
+        std::string e = "encoder." + std::to_string(i);
+        exp[e + ".conv.weight"] = (i64)C * cin * kt;
+        exp[e + ".conv.bias"] = C;
+        exp[e + ".norm1.weight"] = C;
+        exp[e + ".norm1.bias"] = C;
+        exp[e + ".rewrite.weight"] = (i64)2 * C * C;
+        exp[e + ".rewrite.bias"] = 2 * C;
+        exp[e + ".norm2.weight"] = 2 * C;
+        exp[e + ".norm2.bias"] = 2 * C;
+        dconv_lstm(e, C);
+    }
+    exp["decoder.0.conv_tr.weight"] = (i64)1536 * 768 * 4;
+    exp["decoder.0.conv_tr.bias"] = 768;
+    exp["decoder.0.norm2.weight"] = 768;
+    exp["decoder.0.norm2.bias"] = 768;
+    exp["decoder.0.rewrite.weight"] = (i64)3072 * 1536 * 3;
+    exp["decoder.0.rewrite.bias"] = 3072;
+    exp["decoder.0.norm1.weight"] = 3072;
+    exp["decoder.0.norm1.bias"] = 3072;
+    exp["decoder.1.conv_tr.weight"] = (i64)768 * 384 * 8;
+    exp["decoder.1.conv_tr.bias"] = 384;
+    exp["decoder.1.norm2.weight"] = 384;
+    exp["decoder.1.norm2.bias"] = 384;
+    exp["decoder.1.rewrite.weight"] = (i64)1536 * 768 * 9;
+    exp["decoder.1.rewrite.bias"] = 1536;
+    exp["decoder.1.norm1.weight"] = 1536;
+    exp["decoder.1.norm1.bias"] = 1536;
+    exp["tdecoder.0.conv_tr.weight"] = (i64)768 * 384 * 8;
+    exp["tdecoder.0.conv_tr.bias"] = 384;
+    exp["tdecoder.0.norm2.weight"] = 384;
+    exp["tdecoder.0.norm2.bias"] = 384;
+    for (int k = 0; k < 4; ++k)
+    {
+        int Cd = ch[3 - k], cf = k < 3 ? ch[2 - k] : 16, ct = k < 3 ? ch[2 - k] : 8;
+        std::string d = "decoder." + std::to_string(k + 2), t = "tdecoder." + std::to_string(k + 1);
+        exp[d + ".conv_tr.weight"] = (i64)Cd * cf * 8;
+        exp[d + ".conv_tr.bias"] = cf;
+        exp[d + ".rewrite.weight"] = (i64)2 * Cd * Cd * 9;
+        exp[d + ".rewrite.bias"] = 2 * Cd;
+        exp[t + ".conv_tr.weight"] = (i64)Cd * ct * 8;
+        exp[t + ".conv_tr.bias"] = ct;
+        exp[t + ".rewrite.weight"] = (i64)2 * Cd * Cd * 3;
+        exp[t + ".rewrite.bias"] = 2 * Cd;
+    }
+    exp["freq_emb.embedding.weight"] = 512 * 48;
+}
+
+static void pack_v3(PackedModel &pm, const std::map<std::string, Raw> &raw);
+
 bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
 {
     FILE *f = fopen(path.c_str(), "rb");
@@ -392,6 +592,12 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
         pm.n_sources = 4;
         pm.dim = 512;
     }
+    else if (magic == 0x646d6333u) // "dmc3": Demucs v3 hdemucs_mmi, model_load.cpp:1335-1340
+    {
+        pm.arch = 3;
+        pm.n_sources = 4;
+        pm.dim = 0;
+    }
     else
     {
         fclose(f);
@@ -399,7 +605,10 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
         return false;
     }
     std::map<std::string, i64> exp;
-    expected_shapes(pm.n_sources, exp);
+    if (pm.arch == 3)
+        expected_shapes_v3(exp);
+    else
+        expected_shapes(pm.n_sources, exp);
     std::map<std::string, Raw> raw;
     for (;;)
     {
@@ -470,6 +679,11 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
         }
 
     // ---------------- pack ----------------
+    if (pm.arch == 3)
+    {
+        pack_v3(pm, raw);
+        return true;
+    }
     Packer P(pm, raw);
     const int ch[4] = {48, 96, 192, 384};
     const int S = pm.n_sources, D = pm.dim;
@@ -550,6 +764,87 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
             P.vec(p + ".gamma_2", p + ".gamma_2.scale", D);
         }
     return true;
+}
+
+// Demucs v3: encoders / tencoders 0-3 and decoders 2-5 / tdecoders 1-4 are packed like their v4 counterparts
+// (DConv hidden width C/4); levels 4 / 5, decoder 0 / 1 and tdecoder 0 are new (plan_v3.cpp).
+static void pack_v3(PackedModel &pm, const std::map<std::string, Raw> &raw)
+{
+    Packer P(pm, raw);
+    const int ch[4] = {48, 96, 192, 384};
+    std::vector<int> taps8 = {0, 1, 2, 3, 4, 5, 6, 7}, taps4 = {0, 1, 2, 3}, taps3 = {0, 1, 2}, tap1 = {0};
+    for (int i = 0; i < 4; ++i)
+    {
+        int C = ch[i], cf = i == 0 ? 4 : ch[i - 1], ct = i == 0 ? 2 : ch[i - 1];
+        for (int br = 0; br < 2; ++br)
+        {
+            std::string p = std::string(br == 0 ? "encoder." : "tencoder.") + std::to_string(i);
+            P.conv(p + ".conv.Wt", p + ".conv.weight", C, br == 0 ? cf : ct, taps8, false);
+            P.vec(p + ".conv.b", p + ".conv.bias", rup(C, 16));
+            P.dconv(p, C, 4);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * C, C, tap1, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+        }
+    }
+    P.vec("freq_emb.table", "freq_emb.embedding.weight", 512 * 48);
+    P.conv("tencoder.4.conv.Wt", "tencoder.4.conv.weight", 768, 384, taps8, false);
+    P.vec("tencoder.4.conv.b", "tencoder.4.conv.bias", 768);
+    for (int i = 4; i < 6; ++i)
+    {
+        const int C = i == 4 ? 768 : 1536;
+        std::string p = "encoder." + std::to_string(i);
+        // encoder.4: Conv2d (8,1) over the 8 frequency rows of a frame = one run of 8*384 floats, k = f*384 + c;
+        // encoder.5: Conv1d k4 s2 p1 over time, k = tap*768 + c
+        P.conv(p + ".conv.Wt", p + ".conv.weight", C, C / 2, i == 4 ? taps8 : taps4, false);
+        P.vec(p + ".conv.b", p + ".conv.bias", C);
+        P.vec(p + ".norm1.w", p + ".norm1.weight", C);
+        P.vec(p + ".norm1.b", p + ".norm1.bias", C);
+        P.dconv_lstm(p, C);
+        P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * C, C, tap1, false);
+        P.vec(p + ".rewrite.b", p + ".rewrite.bias", 2 * C);
+        P.vec(p + ".norm2.w", p + ".norm2.weight", 2 * C);
+        P.vec(p + ".norm2.b", p + ".norm2.bias", 2 * C);
+    }
+    // decoder.0 (shared): Conv1d k3 (plain channel order: GroupNorm(4) sits between the conv and the GLU)
+    P.conv("decoder.0.rewrite.Wt", "decoder.0.rewrite.weight", 3072, 1536, taps3, false);
+    P.vec("decoder.0.rewrite.b", "decoder.0.rewrite.bias", 3072);
+    P.vec("decoder.0.norm1.w", "decoder.0.norm1.weight", 3072);
+    P.vec("decoder.0.norm1.b", "decoder.0.norm1.bias", 3072);
+    P.conv_tr("decoder.0.conv_tr.Wt", "decoder.0.conv_tr.b", "decoder.0.conv_tr.weight", "decoder.0.conv_tr.bias", 4);
+    P.vec("decoder.0.norm2.w", "decoder.0.norm2.weight", 768);
+    P.vec("decoder.0.norm2.b", "decoder.0.norm2.bias", 768);
+    // decoder.1: Conv2d 3x3 on ONE frequency row: the taps kh = 0, 2 only ever meet zero padding, so the packed
+    // matrix keeps kh = 1 (source tap index kh*3 + kw = 3 + kw), K = 3 (kw over T) x 768
+    P.conv("decoder.1.rewrite.Wt", "decoder.1.rewrite.weight", 1536, 768, {3, 4, 5}, false);
+    P.vec("decoder.1.rewrite.b", "decoder.1.rewrite.bias", 1536);
+    P.vec("decoder.1.norm1.w", "decoder.1.norm1.weight", 1536);
+    P.vec("decoder.1.norm1.b", "decoder.1.norm1.bias", 1536);
+    P.conv_tr("decoder.1.conv_tr.Wt", "decoder.1.conv_tr.b", "decoder.1.conv_tr.weight", "decoder.1.conv_tr.bias");
+    P.vec("decoder.1.norm2.w", "decoder.1.norm2.weight", 384);
+    P.vec("decoder.1.norm2.b", "decoder.1.norm2.bias", 384);
+    P.conv_tr("tdecoder.0.conv_tr.Wt", "tdecoder.0.conv_tr.b", "tdecoder.0.conv_tr.weight", "tdecoder.0.conv_tr.bias");
+    P.vec("tdecoder.0.norm2.w", "tdecoder.0.norm2.weight", 384);
+    P.vec("tdecoder.0.norm2.b", "tdecoder.0.norm2.bias", 384);
+    for (int k = 0; k < 4; ++k)
+    {
+        int Cd = ch[3 - k];
+        {
+            std::string p = "decoder." + std::to_string(k + 2);
+            std::vector<int> tm; // 3x3 over (F = kh, T = kw); our K order: s1 = kw over T, then kh over F, then ci
+            for (int kw = 0; kw < 3; ++kw)
+                for (int kh = 0; kh < 3; ++kh)
+                    tm.push_back(kh * 3 + kw);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * Cd, Cd, tm, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+            P.conv_tr(p + ".conv_tr.Wt", p + ".conv_tr.b", p + ".conv_tr.weight", p + ".conv_tr.bias");
+        }
+        {
+            std::string p = "tdecoder." + std::to_string(k + 1);
+            P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * Cd, Cd, taps3, true);
+            P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
+            P.conv_tr(p + ".conv_tr.Wt", p + ".conv_tr.b", p + ".conv_tr.weight", p + ".conv_tr.bias");
+        }
+    }
 }
 
 } // namespace dmx

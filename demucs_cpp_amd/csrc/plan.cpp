@@ -178,6 +178,7 @@ struct Builder
         g.res = g.scale_w = g.epiStats = g.epiW_w = g.epiB_w = g.rowstat = g.table_w = -1;
         g.tableScale = 0.f;
         g.NB = 1;
+        g.trS = 4, g.trOff = 2;
         return g;
     }
     void finish(IGemm &g, bool paired)
@@ -244,7 +245,7 @@ struct Builder
     void dconv(const std::string &p, int stream, i64 y, int B, int P1, int P0, int C, i64 scratchH, i64 rs,
                i64 st1, i64 st2)
     {
-        const int C8 = C / 8, C8p = rup(C8, 4);
+        const int C8 = C / (pm.arch == 3 ? 4 : 8), C8p = rup(C8, 4); // hidden width: compress 8 (v4) / 4 (v3)
         const int G0 = P0 > 1 ? P0 : 1;
         const i64 rows = (i64)P1 * P0;
         for (int j = 0; j < 2; ++j)
@@ -305,6 +306,11 @@ struct Builder
 
 void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
 {
+    if (pm.arch == 3)
+    {
+        build_plan_v3(pm, seg, B, pl);
+        return;
+    }
     Builder b(pm, pl);
     pl.B = B;
     pl.geo = make_geo(seg);
@@ -851,6 +857,29 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
         R(op.ola.statsT, (i64)op.ola.B * 4);
         Wr(op.ola.out, (i64)op.ola.B * op.ola.S * 2 * op.ola.seg);
         break;
+    case OP_GROUP_STATS:
+        R(op.gs.x, (i64)op.gs.B * op.gs.rows * op.gs.C);
+        Wr(op.gs.out, (i64)op.gs.B * op.gs.G * 4);
+        break;
+    case OP_GN_ACT:
+    {
+        const GnAct &g = op.ga;
+        const int Co = g.mode == 2 ? g.C / 2 : g.C;
+        R(g.x, (i64)g.B * g.rowsIn * g.C);
+        R(g.stats, (i64)g.B * g.G * 4);
+        R(g.res, (i64)g.B * g.rowsOut * Co);
+        Wr(g.y, (i64)g.B * g.rowsOut * Co);
+        break;
+    }
+    case OP_LSTM:
+        R(op.lstm.xproj, (i64)op.lstm.B * op.lstm.T * 8 * op.lstm.H);
+        Wr(op.lstm.out, (i64)op.lstm.B * op.lstm.T * 2 * op.lstm.H);
+        Wr(op.lstm.sync, lstm_sync_floats(op.lstm.B, op.lstm.H));
+        break;
+    case OP_LOCAL_ATTN:
+        R(op.la.qkvd, (i64)op.la.B * op.la.T * op.la.ld);
+        Wr(op.la.out, (i64)op.la.B * op.la.T * op.la.H);
+        break;
     default:
         break;
     }
@@ -891,6 +920,492 @@ void compute_deps(Plan &pl)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Demucs v3 (hdemucs_mmi). Restates /root/reference/src/model_inference.cpp:477-856 with its blocks
+// src/encdec.cpp:363-863 and src/layers.cpp:533-1113, src/lstm.cpp:68-147. Levels 0-3 of both branches are
+// the v4 encoder layers with DConv hidden width C/4; the time branch's level 4 is a bare conv injected into the
+// frequency branch's level 4; levels 4 / 5 carry GroupNorm(4 groups) and a DConv with BiLSTM + LocalState;
+// decoders have no DConv; decoder 0 / 1 and tdecoder 0 carry GroupNorm(4 groups).
+i64 lstm_sync_floats(int B, int H)
+{
+    // h exchange granules of the cooperative LSTM kernel (lstm.hip): [2 directions][batch groups of 16][2 parities][H][16]
+    // x 8 bytes {value, tag}
+    const i64 nbg = (B + 15) / 16;
+    return 2 * nbg * 2 * (i64)H * 16 * 2;
+}
+
+void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
+{
+    Builder b(pm, pl);
+    pl.B = B;
+    pl.geo = make_geo(seg);
+    pl.S = 4;
+    pl.D = 0;
+    const Geo &G = pl.geo;
+    const int T = (int)G.le, S = 4;
+    const int ch[4] = {48, 96, 192, 384};
+    const int Fl[5] = {2048, 512, 128, 32, 8};
+    const int L3 = (int)G.Lt[4];
+    const int T5 = (T - 2 + 1) / 2 + 1; // Conv1d k4 s2 p1, ceil form (Q5): ceil((T + 2 - 3 - 1) / 2) + 1
+
+    // ------------------------------------------------------------------ constants
+    pl.zeroOff = b.alloc(64);
+    const i64 cWindow = b.alloc(4096);
+    const i64 cTwiddle = b.alloc(2 * 2048);
+    const int nfr = T + 4;
+    const i64 wssLen = 4096 + 1024 * (i64)(nfr - 1);
+    const i64 cWss = b.alloc(wssLen);
+    pl.constants.assign((size_t)b.top, 0.0f);
+    {
+        float *win = &pl.constants[(size_t)cWindow];
+        static constexpr float PI = 3.14159265359F;
+        float floatN = (float)(4096 + 1);
+        for (int n = 0; n < 4096; ++n)
+            win[n] = 0.5F * (1.0F - cosf(2.0F * PI * (float)n / (floatN - 1)));
+        float *tw = &pl.constants[(size_t)cTwiddle];
+        for (int k = 0; k < 2048; ++k)
+        {
+            double a = -2.0 * M_PI * (double)k / 4096.0;
+            tw[2 * k] = (float)cos(a);
+            tw[2 * k + 1] = (float)sin(a);
+        }
+        float *wss = &pl.constants[(size_t)cWss];
+        for (int i = 0; i < nfr; ++i)
+            for (int j = 0; j < 4096; ++j)
+                wss[(i64)i * 1024 + j] += win[j] * win[j];
+    }
+
+    // ------------------------------------------------------------------ activations
+    pl.mixOff = b.alloc((i64)B * seg * 2);
+    pl.outOff = b.alloc((i64)B * S * 2 * seg);
+    const i64 aXcac = b.alloc((i64)B * T * 2048 * 4);
+    const i64 aRsX = b.alloc((i64)B * T * 2), aRsT = b.alloc((i64)B * T * 2);
+    const i64 aStF = b.alloc((i64)B * 4), aStT = b.alloc((i64)B * 4);
+    b.redScratch[0] = b.alloc((i64)B * 256 * 4);
+    b.redScratch[1] = b.alloc((i64)B * 256 * 4);
+    i64 aY[4], aX[4], aYt[4], aXt[4];
+    for (int i = 0; i < 4; ++i)
+    {
+        aY[i] = b.alloc((i64)B * T * Fl[i + 1] * ch[i]);
+        aX[i] = b.alloc((i64)B * T * Fl[i + 1] * ch[i]);
+        aYt[i] = b.alloc((i64)B * G.Lt[i + 1] * ch[i]);
+        aXt[i] = b.alloc((i64)B * G.Lt[i + 1] * ch[i]);
+    }
+    i64 maxRowsF = 0, maxHF = 0, maxRowsT = 0, maxHT = 0;
+    for (int i = 0; i < 4; ++i)
+    {
+        i64 rf = (i64)B * T * Fl[i + 1], rt = (i64)B * G.Lt[i + 1];
+        maxRowsF = std::max(maxRowsF, rf);
+        maxRowsT = std::max(maxRowsT, rt);
+        maxHF = std::max(maxHF, rf * rup(ch[i] / 4, 4));
+        maxHT = std::max(maxHT, rt * rup(ch[i] / 4, 4));
+    }
+    const int kMaxNB = 16;
+    const i64 aHf = b.alloc(maxHF), aHt = b.alloc(maxHT);
+    const i64 aRsF = b.alloc(maxRowsF * kMaxNB * 2);
+    const i64 aRsTt = b.alloc(maxRowsT * kMaxNB * 2);
+    const i64 aSt1F = b.alloc((i64)B * 512 * 4), aSt2F = b.alloc((i64)B * 512 * 4);
+    const i64 aSt1T = b.alloc((i64)B * 4), aSt2T = b.alloc((i64)B * 4);
+    // levels 4 / 5 ([B][T][C] / [B][T5][C], channels last)
+    const i64 aXt4 = b.alloc((i64)B * T * 768);
+    const i64 aE4 = b.alloc((i64)B * T * 768), aE4n = b.alloc((i64)B * T * 768);
+    const i64 aR4 = b.alloc((i64)B * T * 1536), aX4 = b.alloc((i64)B * T * 768);
+    const i64 aE5 = b.alloc((i64)B * T5 * 1536), aE5n = b.alloc((i64)B * T5 * 1536);
+    const i64 aR5 = b.alloc((i64)B * T5 * 3072), aX5 = b.alloc((i64)B * T5 * 1536);
+    const i64 rowsH = std::max((i64)T * 192, (i64)T5 * 384); // rows x hidden width of the two LSTM DConvs
+    const i64 aLh = b.alloc(B * rowsH), aLym = b.alloc(B * rowsH), aLr = b.alloc(B * rowsH);
+    const i64 aLxp = b.alloc(B * rowsH * 8), aLl0 = b.alloc(B * rowsH * 2), aLl1 = b.alloc(B * rowsH * 2);
+    const i64 aLqkvd = b.alloc((i64)B * std::max((i64)T * (3 * 192 + 16), (i64)T5 * (3 * 384 + 16)));
+    const i64 aLu = b.alloc((i64)B * std::max((i64)T * 1536, (i64)T5 * 3072));
+    const i64 aLsync = b.alloc(lstm_sync_floats(B, 384));
+    const i64 aStG = b.alloc((i64)B * 4 * 4), aStGt = b.alloc((i64)B * 4 * 4);
+    // decoders 0 / 1, tdecoder 0
+    const int Lz0 = 2 * T5 + 2, Lzt = 4 * T + 4;
+    const i64 aD0r = b.alloc((i64)B * T5 * 3072), aD0g = b.alloc((i64)B * T5 * 1536), aD0t = b.alloc((i64)B * Lz0 * 768);
+    const i64 aD1in = b.alloc((i64)B * T * 768), aD1r = b.alloc((i64)B * T * 1536), aPre = b.alloc((i64)B * T * 768);
+    const i64 aD1t = b.alloc((i64)B * T * 8 * 384), aTD0t = b.alloc((i64)B * Lzt * 384);
+    // common decoders
+    i64 aDin[5], aG[4], aTDin[5], aTG[4];
+    for (int k = 0; k < 4; ++k)
+    {
+        int Cd = ch[3 - k];
+        aDin[k] = b.alloc((i64)B * T * Fl[4 - k] * Cd);
+        aG[k] = b.alloc((i64)B * T * Fl[4 - k] * Cd);
+        aTDin[k] = b.alloc((i64)B * G.Lt[4 - k] * Cd);
+        aTG[k] = b.alloc((i64)B * G.Lt[4 - k] * Cd);
+    }
+    aDin[4] = b.alloc((i64)B * T * 2048 * 4 * S);
+    aTDin[4] = b.alloc((i64)B * seg * 2 * S);
+    const i64 aFrames = b.alloc((i64)B * S * 2 * T * 4096);
+
+    // ------------------------------------------------------------------ small op builders
+    auto gstats = [&](const std::string &name, int stream, i64 x, int rows, int C, int Gn) {
+        Op op;
+        op.kind = OP_GROUP_STATS;
+        op.stream = stream;
+        op.name = name;
+        op.gs = GroupStats{x, aStG, B, rows, C, Gn, 1e-5f};
+        pl.ops.push_back(op);
+    };
+    auto gnact = [&](const std::string &name, int stream, i64 x, i64 y, int rowsIn, int C, int Gn, int mode, i64 w, i64 bs,
+                     i64 scale, i64 res, int rowOff, int rowsOut) {
+        Op op;
+        op.kind = OP_GN_ACT;
+        op.stream = stream;
+        op.name = name;
+        op.ga = GnAct{x, y, aStG, res, w, bs, scale, B, rowsIn, C, Gn, mode, rowOff, rowsOut};
+        pl.ops.push_back(op);
+    };
+    // rows x K linear layer on [B][rows][K] (1x1 conv), optional residual
+    auto linear = [&](const std::string &name, int stream, i64 x, int rows, int K, i64 w, i64 bias, int N, i64 y, i64 res) {
+        IGemm g = b.base_gemm();
+        g.B = B, g.P1 = rows, g.P0 = 1;
+        g.x = x, g.L1 = rows, g.L0 = 1, g.Cin = K;
+        g.seg0 = K;
+        g.w_w = w, g.bias_w = bias, g.N = N;
+        g.epi = EPI_LINEAR, g.act = 0;
+        g.y = y, g.ldy = N, g.yBatchStride = (i64)rows * N;
+        g.res = res;
+        b.finish(g, false);
+        b.push_gemm(name, stream, g);
+    };
+    // Conv1d k3 over the rows of [B][rows][C] (dilation d, "same" padding)
+    auto conv_k3 = [&](const std::string &name, int stream, i64 x, int rows, int C, int d, i64 w, i64 bias, int N, i64 y) {
+        IGemm g = b.base_gemm();
+        g.B = B, g.P1 = rows, g.P0 = 1;
+        g.x = x, g.L1 = rows, g.L0 = 1, g.Cin = C;
+        g.S1 = 3, g.dil1 = d, g.pad1 = d;
+        g.seg0 = C;
+        g.w_w = w, g.bias_w = bias, g.N = N;
+        g.epi = EPI_LINEAR, g.act = 0;
+        g.y = y, g.ldy = N, g.yBatchStride = (i64)rows * N;
+        b.finish(g, false);
+        b.push_gemm(name, stream, g);
+    };
+    // DConv with BiLSTM + LocalState, in place on y [B][rows][C]; layers.cpp:877-1113
+    auto dconv_lstm = [&](const std::string &p, i64 y, int rows, int C, const std::string &tapName) {
+        const int H = C / 4, ld = 3 * H + 16;
+        for (int j = 0; j < 2; ++j)
+        {
+            const std::string w = p + ".dconv." + std::to_string(j) + ".", nm = p + ".dconv" + std::to_string(j);
+            // LSTM and LocalState outputs of every layer keep their own (small) buffers: they are debug taps
+            const i64 aLa = b.alloc((i64)B * rows * H), aLa2 = b.alloc((i64)B * rows * H);
+            conv_k3(nm + ".k1", 0, y, rows, C, j == 0 ? 1 : 2, b.W(w + "k1.Wt"), b.W(w + "k1.b"), H, aLh);
+            gstats(nm + ".gn1.stats", 0, aLh, rows, H, 1);
+            gnact(nm + ".gn1", 0, aLh, aLym, rows, H, 1, 1, b.W(w + "gn1.w"), b.W(w + "gn1.b"), -1, -1, 0, rows);
+            i64 in = aLym;
+            int In = H;
+            for (int layer = 0; layer < 2; ++layer)
+            {
+                const std::string lw = w + "lstm" + std::to_string(layer);
+                linear(nm + ".lstm" + std::to_string(layer) + ".ih", 0, in, rows, In, b.W(lw + ".ih.Wt"), b.W(lw + ".ih.b"), 8 * H,
+                       aLxp, -1);
+                Op op;
+                op.kind = OP_LSTM;
+                op.stream = 0;
+                op.name = nm + ".lstm" + std::to_string(layer);
+                op.lstm = Lstm{aLxp, b.W(lw + ".hh"), layer == 0 ? aLl0 : aLl1, aLsync, B, rows, H};
+                pl.ops.push_back(op);
+                in = layer == 0 ? aLl0 : aLl1;
+                In = 2 * H;
+            }
+            linear(nm + ".lin", 0, aLl1, rows, 2 * H, b.W(w + "lin.Wt"), b.W(w + "lin.b"), H, aLa, aLym); // + skip
+            b.push_tap(tapName + "_lstm" + std::to_string(j), aLa, {rows, H}, (i64)rows * H);
+            linear(nm + ".qkvd", 0, aLa, rows, H, b.W(w + "qkvd.Wt"), b.W(w + "qkvd.b"), ld, aLqkvd, -1);
+            {
+                Op op;
+                op.kind = OP_LOCAL_ATTN;
+                op.stream = 0;
+                op.name = nm + ".attn";
+                op.la = LocalAttn{aLqkvd, aLr, B, rows, H, ld};
+                pl.ops.push_back(op);
+            }
+            linear(nm + ".proj", 0, aLr, rows, H, b.W(w + "proj.Wt"), b.W(w + "proj.b"), H, aLa2, aLa); // x + proj(result)
+            b.push_tap(tapName + "_attn" + std::to_string(j), aLa2, {rows, H}, (i64)rows * H);
+            linear(nm + ".k2", 0, aLa2, rows, H, b.W(w + "k2.Wt"), b.W(w + "k2.b"), 2 * C, aLu, -1);
+            gstats(nm + ".gn2.stats", 0, aLu, rows, 2 * C, 1);
+            gnact(nm + ".gn2", 0, aLu, y, rows, 2 * C, 1, 2, b.W(w + "gn2.w"), b.W(w + "gn2.b"), b.W(w + "scale"), y, 0, rows);
+        }
+    };
+
+    // ------------------------------------------------------------------ ops: front end
+    {
+        Op op;
+        op.kind = OP_STFT;
+        op.stream = 0;
+        op.name = "stft";
+        op.stft = Stft{pl.mixOff, aXcac, aRsX, aRsT, B, T, (int)seg, (int)G.pad, cWindow, cTwiddle};
+        pl.ops.push_back(op);
+    }
+    b.push_reduce("znorm.freq", 0, aRsX, aStF, B, T, 1, 1, (double)4 * 2048 * T, MODE_ZNORM);
+    b.push_reduce("znorm.time", 1, aRsT, aStT, B, T, 1, 1, (double)2 * seg, MODE_ZNORM);
+    b.push_tap("x_cac", aXcac, {T, 2048, 4}, (i64)T * 2048 * 4);
+
+    // ------------------------------------------------------------------ encoders 0-3 (encdec.cpp:363-524)
+    for (int i = 0; i < 4; ++i)
+    {
+        const int C = ch[i], Fin = Fl[i], Fo = Fl[i + 1];
+        const int cinF = i == 0 ? 4 : ch[i - 1], cinT = i == 0 ? 2 : ch[i - 1];
+        const i64 Lin = G.Lt[i], Lo = G.Lt[i + 1];
+        std::string pe = "encoder." + std::to_string(i), pt = "tencoder." + std::to_string(i);
+        {
+            IGemm g = b.base_gemm();
+            g.B = B, g.P1 = 1, g.P0 = (int)Lo;
+            g.x = i == 0 ? pl.mixOff : aXt[i - 1];
+            g.L1 = 1, g.L0 = (int)Lin, g.Cin = cinT;
+            g.seg0 = 8 * cinT, g.stride0 = 4, g.pad0 = 2;
+            if (i == 0)
+                g.pro = PRO_AFFINE, g.proStats = aStT;
+            g.w_w = b.W(pt + ".conv.Wt"), g.bias_w = b.W(pt + ".conv.b");
+            g.N = C;
+            g.epi = EPI_LINEAR, g.act = 1;
+            g.y = aYt[i], g.ldy = C, g.yBatchStride = Lo * C;
+            b.finish(g, false);
+            b.push_gemm(pt + ".conv", 1, g);
+            b.dconv(pt, 1, aYt[i], B, (int)Lo, 1, C, aHt, aRsTt, aSt1T, aSt2T);
+            IGemm r = b.base_gemm();
+            r.B = B, r.P1 = (int)Lo, r.P0 = 1;
+            r.x = aYt[i], r.L1 = (int)Lo, r.L0 = 1, r.Cin = C;
+            r.seg0 = C;
+            r.w_w = b.W(pt + ".rewrite.Wt"), r.bias_w = b.W(pt + ".rewrite.b");
+            r.N = 2 * C;
+            r.epi = EPI_GLU;
+            r.y = aXt[i], r.ldy = C, r.yBatchStride = Lo * C;
+            b.finish(r, true);
+            b.push_gemm(pt + ".rewrite", 1, r);
+        }
+        {
+            IGemm g = b.base_gemm();
+            g.B = B, g.P1 = T, g.P0 = Fo;
+            g.x = i == 0 ? aXcac : aX[i - 1];
+            g.L1 = T, g.L0 = Fin, g.Cin = cinF;
+            g.seg0 = 8 * cinF, g.stride0 = 4, g.pad0 = 2;
+            if (i == 0)
+                g.pro = PRO_AFFINE, g.proStats = aStF;
+            g.w_w = b.W(pe + ".conv.Wt"), g.bias_w = b.W(pe + ".conv.b");
+            g.N = C;
+            g.epi = EPI_LINEAR, g.act = 1;
+            g.y = aY[i], g.ldy = C, g.yBatchStride = (i64)T * Fo * C;
+            b.finish(g, false);
+            b.push_gemm(pe + ".conv", 0, g);
+            b.dconv(pe, 0, aY[i], B, T, Fo, C, aHf, aRsF, aSt1F, aSt2F);
+            IGemm r = b.base_gemm();
+            r.B = B, r.P1 = T, r.P0 = Fo;
+            r.x = aY[i], r.L1 = T, r.L0 = Fo, r.Cin = C;
+            r.seg0 = C;
+            r.w_w = b.W(pe + ".rewrite.Wt"), r.bias_w = b.W(pe + ".rewrite.b");
+            r.N = 2 * C;
+            r.epi = EPI_GLU;
+            if (i == 0)
+                r.table_w = b.W("freq_emb.table"), r.tableScale = 10.0f * 0.2f; // model_inference.cpp:599-618
+            r.y = aX[i], r.ldy = C, r.yBatchStride = (i64)T * Fo * C;
+            b.finish(r, true);
+            b.push_gemm(pe + ".rewrite", 0, r);
+        }
+        b.push_tap("x_" + std::to_string(i), aX[i], {T, Fo, C}, (i64)T * Fo * C);
+        b.push_tap("xt_" + std::to_string(i), aXt[i], {(int)Lo, C}, Lo * C);
+    }
+
+    // ------------------------------------------------------------------ tencoder 4 (bare conv; encdec.cpp:526-537)
+    {
+        IGemm g = b.base_gemm();
+        g.B = B, g.P1 = 1, g.P0 = T;
+        g.x = aXt[3], g.L1 = 1, g.L0 = L3, g.Cin = 384;
+        g.seg0 = 8 * 384, g.stride0 = 4, g.pad0 = 2;
+        g.w_w = b.W("tencoder.4.conv.Wt"), g.bias_w = b.W("tencoder.4.conv.b");
+        g.N = 768;
+        g.epi = EPI_LINEAR, g.act = 0;
+        g.y = aXt4, g.ldy = 768, g.yBatchStride = (i64)T * 768;
+        b.finish(g, false);
+        b.push_gemm("tencoder.4.conv", 1, g);
+        b.push_tap("xt_4", aXt4, {T, 768}, (i64)T * 768);
+    }
+    // ------------------------------------------------------------------ encoder 4 (encdec.cpp:539-581)
+    // Conv2d (8,1)/(4,1), no padding, on the 8 frequency rows of a frame: one run of 8*384 floats per (b, t);
+    // the time branch's level-4 output is injected as the residual of the same GEMM
+    linear("encoder.4.conv", 0, aX[3], T, 8 * 384, b.W("encoder.4.conv.Wt"), b.W("encoder.4.conv.b"), 768, aE4, aXt4);
+    gstats("encoder.4.norm1.stats", 0, aE4, T, 768, 4);
+    gnact("encoder.4.norm1", 0, aE4, aE4n, T, 768, 4, 1, b.W("encoder.4.norm1.w"), b.W("encoder.4.norm1.b"), -1, -1, 0, T);
+    dconv_lstm("encoder.4", aE4n, T, 768, "e4");
+    linear("encoder.4.rewrite", 0, aE4n, T, 768, b.W("encoder.4.rewrite.Wt"), b.W("encoder.4.rewrite.b"), 1536, aR4, -1);
+    gstats("encoder.4.norm2.stats", 0, aR4, T, 1536, 4);
+    gnact("encoder.4.norm2", 0, aR4, aX4, T, 1536, 4, 2, b.W("encoder.4.norm2.w"), b.W("encoder.4.norm2.b"), -1, -1, 0, T);
+    b.push_tap("x_4", aX4, {T, 768}, (i64)T * 768);
+    // ------------------------------------------------------------------ encoder 5, shared (encdec.cpp:583-623)
+    {
+        IGemm g = b.base_gemm(); // Conv1d(768 -> 1536, k4, s2, p1)
+        g.B = B, g.P1 = 1, g.P0 = T5;
+        g.x = aX4, g.L1 = 1, g.L0 = T, g.Cin = 768;
+        g.seg0 = 4 * 768, g.stride0 = 2, g.pad0 = 1;
+        g.w_w = b.W("encoder.5.conv.Wt"), g.bias_w = b.W("encoder.5.conv.b");
+        g.N = 1536;
+        g.epi = EPI_LINEAR, g.act = 0;
+        g.y = aE5, g.ldy = 1536, g.yBatchStride = (i64)T5 * 1536;
+        b.finish(g, false);
+        b.push_gemm("encoder.5.conv", 0, g);
+    }
+    gstats("encoder.5.norm1.stats", 0, aE5, T5, 1536, 4);
+    gnact("encoder.5.norm1", 0, aE5, aE5n, T5, 1536, 4, 1, b.W("encoder.5.norm1.w"), b.W("encoder.5.norm1.b"), -1, -1, 0, T5);
+    dconv_lstm("encoder.5", aE5n, T5, 1536, "e5");
+    linear("encoder.5.rewrite", 0, aE5n, T5, 1536, b.W("encoder.5.rewrite.Wt"), b.W("encoder.5.rewrite.b"), 3072, aR5, -1);
+    gstats("encoder.5.norm2.stats", 0, aR5, T5, 3072, 4);
+    gnact("encoder.5.norm2", 0, aR5, aX5, T5, 3072, 4, 2, b.W("encoder.5.norm2.w"), b.W("encoder.5.norm2.b"), -1, -1, 0, T5);
+    b.push_tap("x_5", aX5, {T5, 1536}, (i64)T5 * 1536);
+
+    // ------------------------------------------------------------------ decoder 0, shared (encdec.cpp:625-663)
+    conv_k3("decoder.0.rewrite", 0, aX5, T5, 1536, 1, b.W("decoder.0.rewrite.Wt"), b.W("decoder.0.rewrite.b"), 3072, aD0r);
+    gstats("decoder.0.norm1.stats", 0, aD0r, T5, 3072, 4);
+    gnact("decoder.0.norm1", 0, aD0r, aD0g, T5, 3072, 4, 2, b.W("decoder.0.norm1.w"), b.W("decoder.0.norm1.b"), -1, -1, 0, T5);
+    {
+        IGemm t = b.base_gemm(); // ConvTranspose1d(1536 -> 768, k4, s2): 2*T5 + 2 outputs, all of them normalised
+        t.B = B, t.P1 = 1, t.P0 = T5 + 1;
+        t.x = aD0g, t.L1 = 1, t.L0 = T5, t.Cin = 1536;
+        t.seg0 = 2 * 1536, t.pad0 = 1;
+        t.w_w = b.W("decoder.0.conv_tr.Wt"), t.bias_w = b.W("decoder.0.conv_tr.b");
+        t.N = 2 * 768;
+        t.epi = EPI_TRCONV, t.act = 0;
+        t.Lout = Lz0, t.Cout = 768, t.trS = 2, t.trOff = 0;
+        t.y = aD0t, t.ldy = 768, t.yBatchStride = (i64)Lz0 * 768;
+        b.finish(t, false);
+        b.push_gemm("decoder.0.conv_tr", 0, t);
+    }
+    gstats("decoder.0.norm2.stats", 0, aD0t, Lz0, 768, 4);
+    // GELU, crop [1, 1+T), and the skip add of decoder 1 (x + saved_4; encdec.cpp:673)
+    gnact("decoder.0.norm2", 0, aD0t, aD1in, Lz0, 768, 4, 1, b.W("decoder.0.norm2.w"), b.W("decoder.0.norm2.b"), -1, aX4, 1, T);
+    b.push_tap("d1_in", aD1in, {T, 768}, (i64)T * 768);
+    // ------------------------------------------------------------------ decoder 1 (encdec.cpp:665-705)
+    conv_k3("decoder.1.rewrite", 0, aD1in, T, 768, 1, b.W("decoder.1.rewrite.Wt"), b.W("decoder.1.rewrite.b"), 1536, aD1r);
+    gstats("decoder.1.norm1.stats", 0, aD1r, T, 1536, 4);
+    gnact("decoder.1.norm1", 0, aD1r, aPre, T, 1536, 4, 2, b.W("decoder.1.norm1.w"), b.W("decoder.1.norm1.b"), -1, -1, 0, T);
+    {
+        IGemm t = b.base_gemm(); // ConvTranspose2d (8,1)/(4,1) on ONE frequency row -> 8 rows, no crop
+        t.B = B, t.P1 = T, t.P0 = 2;
+        t.x = aPre, t.L1 = T, t.L0 = 1, t.Cin = 768;
+        t.seg0 = 2 * 768, t.pad0 = 1;
+        t.w_w = b.W("decoder.1.conv_tr.Wt"), t.bias_w = b.W("decoder.1.conv_tr.b");
+        t.N = 4 * 384;
+        t.epi = EPI_TRCONV, t.act = 0;
+        t.Lout = 8, t.Cout = 384, t.trS = 4, t.trOff = 0;
+        t.y = aD1t, t.ldy = 384, t.yBatchStride = (i64)T * 8 * 384;
+        b.finish(t, false);
+        b.push_gemm("decoder.1.conv_tr", 0, t);
+    }
+    gstats("decoder.1.norm2.stats", 0, aD1t, T * 8, 384, 4);
+    gnact("decoder.1.norm2", 0, aD1t, aDin[0], T * 8, 384, 4, 1, b.W("decoder.1.norm2.w"), b.W("decoder.1.norm2.b"), -1, aX[3], 0,
+          T * 8);
+    b.push_tap("dec_in", aDin[0], {T, 8, 384}, (i64)T * 8 * 384);
+    // ------------------------------------------------------------------ tdecoder 0 (encdec.cpp:707-725)
+    {
+        IGemm t = b.base_gemm(); // ConvTranspose1d(768 -> 384, k8, s4) on decoder 1's "pre": 4T + 4 outputs
+        t.B = B, t.P1 = 1, t.P0 = T + 1;
+        t.x = aPre, t.L1 = 1, t.L0 = T, t.Cin = 768;
+        t.seg0 = 2 * 768, t.pad0 = 1;
+        t.w_w = b.W("tdecoder.0.conv_tr.Wt"), t.bias_w = b.W("tdecoder.0.conv_tr.b");
+        t.N = 4 * 384;
+        t.epi = EPI_TRCONV, t.act = 0;
+        t.Lout = Lzt, t.Cout = 384, t.trS = 4, t.trOff = 0;
+        t.y = aTD0t, t.ldy = 384, t.yBatchStride = (i64)Lzt * 384;
+        b.finish(t, false);
+        b.push_gemm("tdecoder.0.conv_tr", 1, t);
+    }
+    {
+        // the one GroupNorm of the time branch runs on stream 1: its statistics record is its own
+        Op op;
+        op.kind = OP_GROUP_STATS;
+        op.stream = 1;
+        op.name = "tdecoder.0.norm2.stats";
+        op.gs = GroupStats{aTD0t, aStGt, B, Lzt, 384, 4, 1e-5f};
+        pl.ops.push_back(op);
+        // GELU, crop [2, 2 + L3), and the skip add of tdecoder 1
+        Op o2;
+        o2.kind = OP_GN_ACT;
+        o2.stream = 1;
+        o2.name = "tdecoder.0.norm2";
+        o2.ga = GnAct{aTD0t, aTDin[0], aStGt, aXt[3], b.W("tdecoder.0.norm2.w"), b.W("tdecoder.0.norm2.b"), -1, B, Lzt, 384, 4, 1, 2, L3};
+        pl.ops.push_back(o2);
+    }
+    b.push_tap("tdec_in", aTDin[0], {L3, 384}, (i64)L3 * 384);
+
+    // ------------------------------------------------------------------ decoders 2-5 / tdecoders 1-4 (encdec.cpp:727-863)
+    for (int k = 0; k < 4; ++k)
+    {
+        const int Cd = ch[3 - k], F = Fl[4 - k];
+        const int coutF = k < 3 ? ch[2 - k] : 4 * S, coutT = k < 3 ? ch[2 - k] : 2 * S;
+        const i64 L = G.Lt[4 - k], Lout = G.Lt[3 - k];
+        std::string pd = "decoder." + std::to_string(k + 2), ptd = "tdecoder." + std::to_string(k + 1);
+        {
+            IGemm g = b.base_gemm(); // Conv2d 3x3 pad 1 + GLU
+            g.B = B, g.P1 = T, g.P0 = F;
+            g.x = aDin[k], g.L1 = T, g.L0 = F, g.Cin = Cd;
+            g.S1 = 3, g.pad1 = 1;
+            g.seg0 = 3 * Cd, g.pad0 = 1;
+            g.w_w = b.W(pd + ".rewrite.Wt"), g.bias_w = b.W(pd + ".rewrite.b");
+            g.N = 2 * Cd;
+            g.epi = EPI_GLU;
+            g.y = aG[k], g.ldy = Cd, g.yBatchStride = (i64)T * F * Cd;
+            b.finish(g, true);
+            b.push_gemm(pd + ".rewrite", 0, g);
+            IGemm t = b.base_gemm(); // ConvTranspose2d (8,1)/(4,1) (+GELU) + crop + next skip
+            t.B = B, t.P1 = T, t.P0 = F + 1;
+            t.x = aG[k], t.L1 = T, t.L0 = F, t.Cin = Cd;
+            t.seg0 = 2 * Cd, t.pad0 = 1;
+            t.w_w = b.W(pd + ".conv_tr.Wt"), t.bias_w = b.W(pd + ".conv_tr.b");
+            t.N = 4 * coutF;
+            t.epi = EPI_TRCONV, t.act = k < 3 ? 1 : 0;
+            t.Lout = 4 * F, t.Cout = coutF;
+            t.res = k < 3 ? aX[2 - k] : -1;
+            t.y = aDin[k + 1], t.ldy = coutF, t.yBatchStride = (i64)T * 4 * F * coutF;
+            b.finish(t, false);
+            b.push_gemm(pd + ".conv_tr", 0, t);
+            b.push_tap("dec_" + std::to_string(k), aDin[k + 1], {T, 4 * F, coutF}, (i64)T * 4 * F * coutF);
+        }
+        {
+            IGemm g = b.base_gemm(); // Conv1d k3 pad 1 + GLU
+            g.B = B, g.P1 = (int)L, g.P0 = 1;
+            g.x = aTDin[k], g.L1 = (int)L, g.L0 = 1, g.Cin = Cd;
+            g.S1 = 3, g.pad1 = 1;
+            g.seg0 = Cd;
+            g.w_w = b.W(ptd + ".rewrite.Wt"), g.bias_w = b.W(ptd + ".rewrite.b");
+            g.N = 2 * Cd;
+            g.epi = EPI_GLU;
+            g.y = aTG[k], g.ldy = Cd, g.yBatchStride = L * Cd;
+            b.finish(g, true);
+            b.push_gemm(ptd + ".rewrite", 1, g);
+            IGemm t = b.base_gemm();
+            t.B = B, t.P1 = 1, t.P0 = (int)L + 1;
+            t.x = aTG[k], t.L1 = 1, t.L0 = (int)L, t.Cin = Cd;
+            t.seg0 = 2 * Cd, t.pad0 = 1;
+            t.w_w = b.W(ptd + ".conv_tr.Wt"), t.bias_w = b.W(ptd + ".conv_tr.b");
+            t.N = 4 * coutT;
+            t.epi = EPI_TRCONV, t.act = k < 3 ? 1 : 0;
+            t.Lout = (int)Lout, t.Cout = coutT;
+            t.res = k < 3 ? aXt[2 - k] : -1;
+            t.y = aTDin[k + 1], t.ldy = coutT, t.yBatchStride = Lout * coutT;
+            b.finish(t, false);
+            b.push_gemm(ptd + ".conv_tr", 1, t);
+            b.push_tap("tdec_" + std::to_string(k), aTDin[k + 1], {(int)Lout, coutT}, Lout * coutT);
+        }
+    }
+
+    // ------------------------------------------------------------------ ISTFT + sum (model_inference.cpp:719-855)
+    {
+        Op op;
+        op.kind = OP_ISTFT;
+        op.stream = 0;
+        op.name = "istft";
+        op.istft = Istft{aDin[4], aStF, aFrames, B, T, S, cWindow, cTwiddle, 1};
+        pl.ops.push_back(op);
+        Op o2;
+        o2.kind = OP_OLA;
+        o2.stream = 0;
+        o2.name = "ola";
+        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle};
+        pl.ops.push_back(o2);
+    }
+    pl.arenaFloats = b.top + 64;
+    compute_deps(pl);
 }
 
 } // namespace dmx

@@ -38,6 +38,11 @@ enum OpKind
     OP_ISTFT,
     OP_OLA,
     OP_TAP, // no-op marker: names an activation for the debug-tap API
+    // ---- Demucs v3 (hdemucs_mmi) levels 4 / 5 and its decoders (plan_v3.cpp)
+    OP_GROUP_STATS, // GroupNorm statistics of G channel groups straight from the tensor
+    OP_GN_ACT,      // GroupNorm apply (+GELU | +GLU (+LayerScale, residual)) with an optional row crop
+    OP_LSTM,        // one bidirectional LSTM layer (recurrent part; the input projection is an OP_IGEMM)
+    OP_LOCAL_ATTN,  // LocalState attention core (scores + decay + softmax over keys + weighted content)
 };
 
 enum Prologue
@@ -103,6 +108,8 @@ struct IGemm
     i64 table_w;              // W: [P0][C] (EPI_GLU freq-embedding add) or -1
     float tableScale;
     int Lout, Cout;           // EPI_TRCONV: output positions per (b,p1) row, channels
+    int trS, trOff;           // EPI_TRCONV: n = (r, co), r < trS; output position j = trS*p0 + r - trOff
+                              // (k8/s4 with the 2-sample crop: 4, 2; v3's uncropped k8/s4: 4, 0; k4/s2: 2, 0)
     int cfg;                  // tile configuration index (engine)
 };
 
@@ -179,6 +186,50 @@ struct Ola
     i64 x, stats, window, twiddle; // operands of the preceding OP_ISTFT (fused execution), -1 otherwise
 };
 
+// ---- Demucs v3 ops. Tensors are [B][rows][C] channels-last like everything else.
+// GroupNorm statistics (UNBIASED variance, Q3) of G groups: group g = channels [g*C/G, (g+1)*C/G) over ALL rows of a
+// batch element (/root/reference/src/layers.hpp:125-168; rows = T, or T*8 for decoder.1's norm2).
+struct GroupStats
+{
+    i64 x;   // A: [B][rows][C]
+    i64 out; // A: [B][G][4] {mean, rstd, std, 0}
+    int B, rows, C, G;
+    float eps;
+};
+// y[b][r][c'] = f(x[b][r + rowOff][.]) for r < rowsOut:
+//   mode 0: v = gn(x[c]);  mode 1: v = gelu(gn(x[c]));  mode 2 (GLU): v = gn(x[c]) * sigmoid(gn(x[c + C/2])), C' = C/2;
+//   then if scale_w >= 0: v *= scale[c'];  if res >= 0: v += res[b][r][c'].
+//   gn(x[c]) = (x - mean_g) * rstd_g * w[c] + b[c], g = c / (C/G).
+struct GnAct
+{
+    i64 x, y, stats, res; // A (res may alias y)
+    i64 w_w, b_w, scale_w; // W ([C], [C], [C/2] or -1)
+    int B, rowsIn, C, G, mode, rowOff, rowsOut;
+};
+// One bidirectional LSTM layer, zero initial state (/root/reference/src/lstm.cpp:68-147). The input projection
+// xproj = x W_ih^T + (b_ih + b_hh) of BOTH directions comes from an OP_IGEMM: [B][T][2][4H] with the gate rows of a
+// direction in (unit, gate) order: column 4*j + g, g = i|f|g|o. whh: [2][4H][H] in the same row order.
+// out[b][t][dir*H + j] = h_t of direction dir (forward | backward concatenated, lstm.cpp:136-143).
+struct Lstm
+{
+    i64 xproj; // A: [B][T][8H]
+    i64 whh_w; // W: [2][4H][H]
+    i64 out;   // A: [B][T][2H]
+    i64 sync;  // A: scratch of the cooperative kernel (h exchange granules), zeroed by the launcher; >= lstm_sync_floats(B, H) floats
+    int B, T, H;
+};
+i64 lstm_sync_floats(int B, int H);
+// LocalState attention core (/root/reference/src/layers.cpp:533-721), heads = 4, 4 decay rates.
+// qkvd: [B][T][ld] = [query H | key H | content H | decay logits 16] per position (one OP_IGEMM).
+// dots(t, s) = q_s . k_t / sqrt(H/4) - sum_n (n+1) |t-s| / 2 * sigmoid(d[s][4h+n]) / 2, diagonal = -100;
+// softmax over the KEY index t per query s; out[s] = sum_t w(t, s) content[t].
+struct LocalAttn
+{
+    i64 qkvd; // A
+    i64 out;  // A: [B][T][H]
+    int B, T, H, ld;
+};
+
 struct Tap
 {
     i64 off;
@@ -203,6 +254,10 @@ struct Op
     Istft istft;
     Ola ola;
     Tap tap;
+    GroupStats gs;
+    GnAct ga;
+    Lstm lstm;
+    LocalAttn la;
 };
 
 // geometry of one segment (model.hpp:19-24,618-625 generalised to any length)
@@ -215,6 +270,7 @@ Geo make_geo(i64 seg);
 
 struct PackedModel
 {
+    int arch = 4; // 4: HTDemucs v4 (dmc4 / dmc6); 3: Demucs v3 hdemucs_mmi (dmc3)
     int n_sources = 4;
     int dim = 512;
     int n_tensors = 0;
@@ -280,8 +336,9 @@ struct Plan
 
 // model_pack.cpp
 bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err);
-// plan.cpp
+// plan.cpp (v4) / plan_v3.cpp (v3, dispatched from build_plan on pm.arch)
 void build_plan(const PackedModel &pm, i64 seg, int B, Plan &plan);
+void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &plan);
 // arena ranges [lo, hi) an op reads / writes (conservative hulls); constants and W space excluded
 struct Range
 {

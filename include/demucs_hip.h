@@ -56,16 +56,19 @@ extern "C"
     const char *dmx_last_error(void);
     int dmx_device_count(void);
 
-    /* Replaces demucscpp::load_demucs_model (src/model.hpp:649-650, src/model_load.cpp:50):
-     * reads a dmc4/dmc6 ggml-style fp16 weight file, repacks it and uploads it to
-     * `device`. Same failure cases as the reference (open failure, bad magic, unknown
-     * tensor name, element-count mismatch) plus "tensor missing". */
+    /* Replaces demucscpp::load_demucs_model (src/model.hpp:649-650, src/model_load.cpp:50) and
+     * demucscpp_v3::load_demucs_v3_model (src/model.hpp:1396-1397, src/model_load.cpp:1302):
+     * reads a dmc4 / dmc6 (HTDemucs v4) or dmc3 (Demucs v3 hdemucs_mmi) ggml-style fp16 weight file, repacks it
+     * and uploads it to `device`; the magic selects the architecture. Same failure cases as the reference
+     * (open failure, bad magic, unknown tensor name, element-count mismatch) plus "tensor missing". */
     int dmx_model_load(const char *model_file, int device, dmx_model **out);
     void dmx_model_free(dmx_model *m);
     /* the same weights on another device, without re-reading / re-packing the file (one replica per GPU) */
     int dmx_model_clone(const dmx_model *src, int device, dmx_model **out);
     int dmx_model_n_sources(const dmx_model *m); /* 4 or 6 (demucs_model::is_4sources) */
     int dmx_model_n_tensors(const dmx_model *m);
+    /* 4: HTDemucs v4 (dmc4 / dmc6 file); 3: Demucs v3 hdemucs_mmi (dmc3 file). Every other entry point takes either. */
+    int dmx_model_arch(const dmx_model *m);
     int dmx_model_device(const dmx_model *m);
 
     /* Execution context = the reference's demucs_segment_buffers + stft_buffers

@@ -1624,6 +1624,12 @@ static void model_v3_inference(const Model &m, const float *mix, int64_t seg, fl
                 d0.d[(size_t)(c * T + t)] = zb.d[(size_t)(c * Lz + t + 1)];
     }
     tap("d0", d0);
+    {
+        Tensor t = d0; // what the product's fused "crop + skip add" tap holds
+        for (size_t i = 0; i < t.d.size(); ++i)
+            t.d[i] += x4.d[i];
+        tap("d1_in", t);
+    }
     // decoder 1 (freq): (x + skip) -> Conv2d 3x3 + GroupNorm(4) + GLU = pre; ConvTranspose2d (8,1)/(4,1) +
     // GroupNorm(4)+GELU, no crop; encdec.cpp:665-705
     Tensor pre, d1;
@@ -1676,6 +1682,15 @@ static void model_v3_inference(const Model &m, const float *mix, int64_t seg, fl
                 td0.d[(size_t)(c * L3 + l)] = zb.d[(size_t)(c * Lz + l + 2)];
     }
     tap("td0", td0);
+    {
+        Tensor t = d1, tt = td0;
+        for (size_t i = 0; i < t.d.size(); ++i)
+            t.d[i] += saved[3].d[i];
+        for (size_t i = 0; i < tt.d.size(); ++i)
+            tt.d[i] += savedt[3].d[i];
+        tap("dec_in", t);
+        tap("tdec_in", tt);
+    }
     xc = d1;
     xtc = td0;
     for (int k = 0; k < 4; ++k) // model_inference.cpp:685-715

@@ -146,7 +146,7 @@ struct Interp
                 for (int n = 0; n < g.N; ++n)
                 {
                     int r = n / g.Cout, co = n % g.Cout;
-                    int j = 4 * p0 + r - 2;
+                    int j = g.trS * p0 + r - g.trOff;
                     if (j < 0 || j >= g.Lout)
                         continue;
                     float t = v[(size_t)n];
@@ -441,6 +441,148 @@ struct Interp
         return seq;
     }
 
+    // ---- Demucs v3 ops (plan.h)
+    void run_group_stats(const GroupStats &g)
+    {
+        const int gs = g.C / g.G;
+        for (int b = 0; b < g.B; ++b)
+            for (int gi = 0; gi < g.G; ++gi)
+            {
+                const double cnt = (double)g.rows * gs;
+                double sum = 0;
+                for (int r = 0; r < g.rows; ++r)
+                    for (int c = gi * gs; c < (gi + 1) * gs; ++c)
+                        sum += A[(size_t)(g.x + ((i64)b * g.rows + r) * g.C + c)];
+                const float mean = (float)(sum / cnt);
+                double ss = 0;
+                for (int r = 0; r < g.rows; ++r)
+                    for (int c = gi * gs; c < (gi + 1) * gs; ++c)
+                    {
+                        const double d = (double)A[(size_t)(g.x + ((i64)b * g.rows + r) * g.C + c)] - (double)mean;
+                        ss += d * d;
+                    }
+                const double var = ss / (cnt - 1.0);
+                float *o = &A[(size_t)(g.out + ((i64)b * g.G + gi) * 4)];
+                o[0] = mean;
+                o[1] = (float)(1.0 / std::sqrt(var + (double)g.eps));
+                o[2] = (float)std::sqrt(var);
+                o[3] = 0.f;
+            }
+    }
+    void run_gn_act(const GnAct &g)
+    {
+        const int gs = g.C / g.G, Co = g.mode == 2 ? g.C / 2 : g.C;
+        for (int b = 0; b < g.B; ++b)
+            for (int r = 0; r < g.rowsOut; ++r)
+            {
+                const float *x = &A[(size_t)(g.x + ((i64)b * g.rowsIn + r + g.rowOff) * g.C)];
+                auto gn = [&](int c) {
+                    const float *st = &A[(size_t)(g.stats + ((i64)b * g.G + c / gs) * 4)];
+                    return (x[c] - st[0]) * st[1] * W[g.w_w + c] + W[g.b_w + c];
+                };
+                std::vector<float> tmp((size_t)Co);
+                for (int c = 0; c < Co; ++c)
+                {
+                    float v = gn(c);
+                    if (g.mode == 1)
+                        v = gelu(v);
+                    else if (g.mode == 2)
+                        v = v * sigmoidf(gn(c + Co));
+                    if (g.scale_w >= 0)
+                        v *= W[g.scale_w + c];
+                    if (g.res >= 0)
+                        v += A[(size_t)(g.res + ((i64)b * g.rowsOut + r) * Co + c)];
+                    tmp[(size_t)c] = v;
+                }
+                for (int c = 0; c < Co; ++c)
+                    A[(size_t)(g.y + ((i64)b * g.rowsOut + r) * Co + c)] = tmp[(size_t)c];
+            }
+    }
+    void run_lstm(const Lstm &l)
+    {
+        const int H = l.H, T = l.T;
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < l.B; ++b)
+            for (int dir = 0; dir < 2; ++dir)
+            {
+                std::vector<float> h((size_t)H, 0.f), c((size_t)H, 0.f), hn((size_t)H);
+                const float *U = W + l.whh_w + (i64)dir * 4 * H * H;
+                for (int step = 0; step < T; ++step)
+                {
+                    const int t = dir == 0 ? step : T - 1 - step;
+                    const float *xp = &A[(size_t)(l.xproj + ((i64)b * T + t) * 8 * H + (i64)dir * 4 * H)];
+                    for (int j = 0; j < H; ++j)
+                    {
+                        float gt[4];
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            const float *u = U + (i64)(4 * j + q) * H;
+                            float acc = xp[4 * j + q]; // the MFMA accumulates onto the input projection, k ascending
+                            for (int k = 0; k < H; ++k)
+                                acc = std::fmaf(u[k], h[(size_t)k], acc);
+                            gt[q] = acc;
+                        }
+                        const float ig = sigmoidf(gt[0]), fg = sigmoidf(gt[1]), gg = std::tanh(gt[2]), og = sigmoidf(gt[3]);
+                        const float cn = fg * c[(size_t)j] + ig * gg;
+                        c[(size_t)j] = cn;
+                        hn[(size_t)j] = og * std::tanh(cn);
+                    }
+                    h = hn;
+                    for (int j = 0; j < H; ++j)
+                        A[(size_t)(l.out + ((i64)b * T + t) * 2 * H + (i64)dir * H + j)] = h[(size_t)j];
+                }
+            }
+    }
+    void run_local_attn(const LocalAttn &a)
+    {
+        const int heads = 4, nd = 4, hd = a.H / heads, T = a.T;
+        const float sq = std::sqrt((float)hd);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < a.B; ++b)
+            for (int h = 0; h < heads; ++h)
+            {
+                std::vector<float> w((size_t)T);
+                for (int s = 0; s < T; ++s)
+                {
+                    const float *row = &A[(size_t)(a.qkvd + ((i64)b * T + s) * a.ld)];
+                    const float *q = row + h * hd;
+                    float dq[4];
+                    for (int n = 0; n < nd; ++n)
+                        dq[n] = 0.5f * sigmoidf(row[3 * a.H + h * nd + n]);
+                    float mx = -INFINITY;
+                    for (int t = 0; t < T; ++t)
+                    {
+                        const float *k = &A[(size_t)(a.qkvd + ((i64)b * T + t) * a.ld + a.H + h * hd)];
+                        float dot = 0.f;
+                        for (int c = 0; c < hd; ++c)
+                            dot += q[c] * k[c];
+                        float v = dot / sq, decay = 0.f;
+                        const float delta = (float)std::abs(t - s);
+                        for (int n = 0; n < nd; ++n)
+                            decay += (-(float)(n + 1) * delta / 2.0f) * dq[n];
+                        w[(size_t)t] = t != s ? v + decay : -100.0f;
+                        mx = std::max(mx, w[(size_t)t]);
+                    }
+                    float sum = 0.f;
+                    for (int t = 0; t < T; ++t)
+                    {
+                        w[(size_t)t] = std::exp(w[(size_t)t] - mx);
+                        sum += w[(size_t)t];
+                    }
+                    for (int t = 0; t < T; ++t)
+                        w[(size_t)t] /= sum;
+                    float *o = &A[(size_t)(a.out + ((i64)b * T + s) * a.H + h * hd)];
+                    for (int c = 0; c < hd; ++c)
+                    {
+                        float acc = 0.f;
+                        for (int t = 0; t < T; ++t)
+                            acc += w[(size_t)t] * A[(size_t)(a.qkvd + ((i64)b * T + t) * a.ld + 2 * a.H + h * hd + c)];
+                        o[c] = acc;
+                    }
+                }
+            }
+    }
+
     void run(int order = 0)
     {
         for (int idx : schedule(order))
@@ -456,6 +598,10 @@ struct Interp
             case OP_ATTENTION: run_attention(op.at); break;
             case OP_ISTFT: run_istft(op.istft); break;
             case OP_OLA: run_ola(op.ola); break;
+            case OP_GROUP_STATS: run_group_stats(op.gs); break;
+            case OP_GN_ACT: run_gn_act(op.ga); break;
+            case OP_LSTM: run_lstm(op.lstm); break;
+            case OP_LOCAL_ATTN: run_local_attn(op.la); break;
             default: break;
             }
         }

@@ -43,12 +43,42 @@ def oracle_tap(name):
     return orc.tap(name)
 
 
+# Demucs v3 (hdemucs_mmi): product tap -> (oracle tap, transpose of the product's [rows][C] / [T][F][C] image)
+V3_TAPS = (["x_cac"] + [f"{p}_{i}" for i in range(4) for p in ("x", "xt")] +
+           ["xt_4", "e4_lstm0", "e4_attn0", "e4_lstm1", "e4_attn1", "x_4", "e5_lstm0", "e5_attn0", "e5_lstm1", "e5_attn1", "x_5",
+            "d1_in", "dec_in", "tdec_in"] + [f"{p}_{k}" for k in range(4) for p in ("dec", "tdec")])
+
+
+def gpu_tap_as_oracle_v3(ctx, name, b=0):
+    a = ctx.tap(name)
+    if a is None:
+        return None
+    a = a[b]
+    return a.transpose(2, 1, 0) if a.ndim == 3 else a.T  # [T][F][C] -> (C,F,T); [rows][C] -> (C,rows)
+
+
+def oracle_tap_v3(name):
+    """Oracle tensor matching what the v3 product tap holds (decoder taps include the fused skip add)."""
+    if name in ("dec_0", "dec_1", "dec_2") or name in ("tdec_0", "tdec_1", "tdec_2"):
+        return np.squeeze(oracle_tap(name))
+    return np.squeeze(orc.tap(name))
+
+
 def compare_segment(ctx, omodel, mix, b=0, taps=True):
     """mix (2, seg). Runs oracle + GPU; returns (errors dict, gpu_out, oracle_out)."""
     ref = omodel.segment(mix, taps=taps)
     out = ctx.segment(mix)
     errs = {}
-    if taps:
+    if taps and getattr(omodel, "arch", 4) == 3:
+        for name in V3_TAPS:
+            g = gpu_tap_as_oracle_v3(ctx, name, b)
+            if g is None:
+                errs[name] = float("nan")
+                continue
+            r = oracle_tap_v3(name)
+            g = np.squeeze(g)
+            errs[name] = relerr(g, r) if g.shape == r.shape else float("nan")
+    elif taps:
         for name in TAPS:
             g = gpu_tap_as_oracle(ctx, name, b)
             if g is None:

@@ -44,7 +44,7 @@ def test_load_missing_file_fails(dmx):
 
 def test_load_bad_magic_fails(dmx, tmp_path):
     p = tmp_path / "bad.bin"
-    p.write_bytes(struct.pack("<I", 0x646D6333) + b"\0" * 64)  # "dmc3" (v3) is out of scope
+    p.write_bytes(struct.pack("<I", 0x646D6335) + b"\0" * 64)  # "dmc5": neither dmc4 / dmc6 (v4) nor dmc3 (v3)
     with pytest.raises(dmx.DmxError) as e:
         dmx.Model(str(p))
     assert e.value.code == 2 and "bad magic" in str(e.value)
@@ -84,6 +84,40 @@ def test_six_source_file_with_four_source_tensor_shapes_fails(dmx, tmp_path):
     _write(tmp_path / "mix.bin", 6, w)
     with pytest.raises(dmx.DmxError) as e:
         dmx.Model(str(tmp_path / "mix.bin"))
+    assert e.value.code == 2
+
+
+def test_v3_file_failure_cases(dmx, tmp_path):
+    """dmc3 (Demucs v3 hdemucs_mmi): same loader contract as the reference's load_demucs_v3_model
+    (/root/reference/src/model_load.cpp:1302-2166) + the missing-tensor check."""
+    from demucs_cpp_amd.weights import synth_weights, write_model
+    w = synth_weights(4, 5, "default", "v3")
+    bad = dict(w)
+    bad["encoder.4.dconv.layers.0.3.lstm.weight_ih_l2"] = np.zeros(3, np.float16)
+    write_model(str(tmp_path / "unk.bin"), bad, 4, "v3")
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "unk.bin"))
+    assert e.value.code == 2 and "failed to load encoder.4.dconv.layers.0.3.lstm.weight_ih_l2" in str(e.value)
+    bad = dict(w)
+    bad["encoder.5.dconv.layers.1.4.query_decay.bias"] = np.zeros(15, np.float16)
+    write_model(str(tmp_path / "size.bin"), bad, 4, "v3")
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "size.bin"))
+    assert e.value.code == 2 and "wrong size" in str(e.value)
+    bad = dict(w)
+    del bad["tdecoder.0.norm2.bias"]
+    write_model(str(tmp_path / "missing.bin"), bad, 4, "v3")
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "missing.bin"))
+    assert e.value.code == 2 and "missing" in str(e.value)
+    # v4 tensors under the v3 magic (and the reverse) are rejected by name
+    write_model(str(tmp_path / "v4as3.bin"), synth_weights(4, 0), 4, "v3")
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "v4as3.bin"))
+    assert e.value.code == 2
+    write_model(str(tmp_path / "v3as4.bin"), w, 4, "v4")
+    with pytest.raises(dmx.DmxError) as e:
+        dmx.Model(str(tmp_path / "v3as4.bin"))
     assert e.value.code == 2
 
 

@@ -36,7 +36,7 @@ def run(L, path, mixes):
     h = L.interp_create(path.encode(), seg, B)
     assert h
     mi = np.ascontiguousarray(mixes.transpose(0, 2, 1)).astype(np.float32)
-    ns = 4 if "4s" in path else 6
+    ns = 6 if "6s" in path else 4  # htdemucs-4s and hdemucs_mmi (v3) separate 4 stems
     out = np.zeros((B, ns, 2, seg), np.float32)
     L.interp_run(h, mi.ctypes.data, out.ctypes.data)
     L.interp_free(h)
@@ -49,6 +49,29 @@ def test_plan_matches_fp64_golden(ns, interp, golden_dir, tmp_models):
     out = run(interp, tmp_models[ns], g["mix"][None])
     err = np.abs(out[0] - g["out"]).max() / np.abs(g["out"]).max()
     assert err < 2e-5, err
+
+
+def test_v3_plan_matches_fp64_golden(interp, golden_dir, tmp_models):
+    """Demucs v3 (hdemucs_mmi): dmc3 packing (LSTM gate interleave, fused LocalState projections, k4/s2 transposed
+    conv) + build_plan_v3, interpreted on the CPU, against the fp64 torch model of tests/golden/make_golden_v3.py."""
+    g = np.load(os.path.join(golden_dir, "golden_seg_v3.npz"))
+    out = run(interp, tmp_models[3], g["mix"][None])
+    err = np.abs(out[0] - g["out"]).max() / np.abs(g["out"]).max()
+    assert err < 2e-5, err
+
+
+def test_v3_plan_batch_and_odd_frames_vs_oracle(interp, tmp_models):
+    rng = np.random.default_rng(31)
+    seg = 7000  # T = 7: encoder.5's ceil-form length and decoder.0's crop on an odd frame count
+    mixes = (0.1 * rng.standard_normal((2, 2, seg))).astype(np.float32)
+    both = run(interp, tmp_models[3], mixes)
+    m = orc.OracleModel(tmp_models[3])
+    for b in range(2):
+        single = run(interp, tmp_models[3], mixes[b:b + 1])
+        assert np.abs(both[b] - single[0]).max() < 1e-6
+        ref = m.segment(mixes[b])
+        assert np.abs(both[b] - ref).max() / np.abs(ref).max() < 2e-5
+    m.close()
 
 
 def test_plan_batch_equals_singles_and_oracle(interp, tmp_models):
@@ -65,7 +88,7 @@ def test_plan_batch_equals_singles_and_oracle(interp, tmp_models):
     m.close()
 
 
-@pytest.mark.parametrize("ns", [4, 6])
+@pytest.mark.parametrize("ns", [4, 6, 3])
 def test_two_stream_waits_cover_every_hazard(ns, interp, tmp_models):
     """The engine runs the freq and time branches on two HIP streams joined only by the waits
     plan.cpp derives from the ops' arena ranges. Executing the plan in the two most skewed
@@ -79,7 +102,7 @@ def test_two_stream_waits_cover_every_hazard(ns, interp, tmp_models):
     for order in (0, 1, 2):
         h = interp.interp_create(tmp_models[ns].encode(), seg, 1)
         nw = interp.interp_n_waits(h)
-        out = np.zeros((1, ns, 2, seg), np.float32)
+        out = np.zeros((1, 6 if ns == 6 else 4, 2, seg), np.float32)  # key 3 = Demucs v3 (4 stems)
         interp.interp_run_order(h, mix.ctypes.data, out.ctypes.data, order)
         interp.interp_free(h)
         outs.append(out)
