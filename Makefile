@@ -19,7 +19,7 @@ $(LIB): $(OBJS)
 	@mkdir -p demucs_cpp_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -lpthread
 
-cli: cli/demucs.cpp.main cli/demucs_ft.cpp.main cli/demucs_mt.cpp.main cli/demucs_ft_mt.cpp.main
+cli: cli/demucs.cpp.main cli/demucs_ft.cpp.main cli/demucs_mt.cpp.main cli/demucs_ft_mt.cpp.main cli/demucs_v3.cpp.main cli/demucs_v3_mt.cpp.main
 cli/%.cpp.main: cli/%_main.cpp $(LIB) demucs_cpp_amd/host/demucscpp_hip.hpp demucs_cpp_amd/host/threaded_inference_hip.hpp cli/wav.hpp
 	g++ -O2 -std=c++17 -Iinclude -Idemucs_cpp_amd/host -o $@ $< -Ldemucs_cpp_amd/lib -ldemucs_hip -lpthread -Wl,-rpath,'$$ORIGIN/../demucs_cpp_amd/lib'
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
-    "dmx_model_arch", "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
+    "dmx_model_arch", "dmx_engine_arch", "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2

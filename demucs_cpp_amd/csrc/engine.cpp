@@ -198,7 +198,16 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
         else if (env && !strcmp(env, "rccl"))
             transport = DMX_TRANSPORT_RCCL;
         else
+        {
             transport = (distinct && devs.size() > 1) ? DMX_TRANSPORT_RCCL : DMX_TRANSPORT_P2P;
+            // AUTO never fails for want of librccl: the peer-copy transport moves the same bytes over the same links
+            if (transport == DMX_TRANSPORT_RCCL)
+            {
+                RcclApi *api = rccl_api();
+                if (!api->handle || !api->why.empty())
+                    transport = DMX_TRANSPORT_P2P;
+            }
+        }
     }
     if (transport != DMX_TRANSPORT_P2P && transport != DMX_TRANSPORT_RCCL)
         return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: unknown transport %d", transport);
@@ -218,8 +227,8 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
             else
                 DMXCHK(dmx_model_clone(e->devs[0].models[(size_t)m], d.dev, &h));
             d.models.push_back(h);
-            if (dmx_model_n_sources(h) != dmx_model_n_sources(d.models[0]))
-                return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the models of a bag must have the same number of sources");
+            if (dmx_model_n_sources(h) != dmx_model_n_sources(d.models[0]) || dmx_model_arch(h) != dmx_model_arch(d.models[0]))
+                return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the models of a bag must have the same architecture and number of sources");
         }
         DMXCHK(dmx_ctx_create(d.models[0], 0, max_batch, &d.ctx));
         for (int m = 1; m < n_models; ++m) // every model must fit the one plan
@@ -278,6 +287,7 @@ extern "C" void dmx_engine_free(dmx_engine *e) { delete e; }
 extern "C" int dmx_engine_n_devices(const dmx_engine *e) { return e ? (int)e->devs.size() : 0; }
 extern "C" int dmx_engine_n_models(const dmx_engine *e) { return e ? e->nModels : 0; }
 extern "C" int dmx_engine_n_sources(const dmx_engine *e) { return e ? e->S : 0; }
+extern "C" int dmx_engine_arch(const dmx_engine *e) { return e && !e->devs.empty() ? dmx_model_arch(e->devs[0].models[0]) : 0; }
 extern "C" int dmx_engine_transport(const dmx_engine *e) { return e ? e->transport : -1; }
 extern "C" int dmx_engine_finish(const dmx_engine *e) { return e ? e->finish : -1; }
 extern "C" int dmx_engine_set_finish(dmx_engine *e, int finish)

@@ -6,6 +6,10 @@
 //   <S,2,N> demucscpp::demucs_inference(const demucs_model&, <2,N>, ProgressCallback) :658-660
 //   void  demucscpp::model_inference(const demucs_model&, demucs_segment_buffers&,
 //                                    stft_buffers&, ProgressCallback, float, float) :662-666
+// and, for Demucs v3 (hdemucs_mmi), namespace demucscpp_v3 (src/model.hpp:668-1415):
+//   bool  load_demucs_v3_model(const std::string&, demucs_v3_model*)                     :1396-1397
+//   <4,2,N> demucs_v3_inference(const demucs_v3_model&, <2,N>, ProgressCallback)          :1405-1408
+//   void  model_v3_inference(const demucs_v3_model&, demucs_v3_segment_buffers&, stft_buffers&, ...) :1410-1414
 //
 // Eigen is not required: the two tensor types below have exactly the memory image of
 // the reference's column-major Eigen::MatrixXf(2,N) and Eigen::Tensor3dXf(S,2,N), so a
@@ -73,22 +77,25 @@ struct StemTensor
 // (cli-apps/threaded_inference.hpp:105-123 runs N std::threads on it). Calls on one demucs_model are
 // serialised here by `lock` (one GPU context already keeps every CU busy, so nothing is lost); results are
 // bit-identical to sequential calls. tests/threaded_harness.cpp runs exactly that pattern.
-struct demucs_model
+struct engine_model // what a loaded model is on this side of the boundary, whatever its architecture
 {
-    bool is_4sources = true;
     std::vector<int> devices;  // HIP devices (env DMX_DEVICES="0,1,..."; "all"; default: device DMX_DEVICE or 0)
     int shift_offset = -1;     // -1: rand() % 22050 like src/model_apply.cpp:114; else fixed
     int max_batch = 12;        // segments in flight per device (7.8 GB of arena; 3.33 ms per segment, 3.9 at 4, 3.22 at 24: DMX_BATCH)
     dmx_engine *engine = nullptr;
     mutable std::mutex lock;
-    demucs_model() {}
-    demucs_model(const demucs_model &) = delete;
-    demucs_model &operator=(const demucs_model &) = delete;
-    ~demucs_model()
+    engine_model() {}
+    engine_model(const engine_model &) = delete;
+    engine_model &operator=(const engine_model &) = delete;
+    ~engine_model()
     {
         if (engine)
             dmx_engine_free(engine);
     }
+};
+struct demucs_model : engine_model
+{
+    bool is_4sources = true;
 };
 
 namespace detail
@@ -147,18 +154,36 @@ inline void progress_thunk(float p, const char *msg, void *user)
 // src/model.hpp:649-650. Returns false and reports on stderr exactly when the reference
 // loader does (src/model_load.cpp:64-69,97-102,1065-1070,1096-1105), and additionally
 // when no HIP device is usable (there is no CPU fallback).
-inline bool load_demucs_model(const std::string &model_file, demucs_model *model)
+namespace detail
+{
+// arch: 4 = dmc4 / dmc6 file (HTDemucs v4), 3 = dmc3 (Demucs v3). A file of the other family is "bad magic" to the
+// reference's loaders (src/model_load.cpp:79-102 / :1335-1340).
+inline bool load_engine(const char *who, const std::string &model_file, engine_model *model, int arch)
 {
     if (model->devices.empty())
-        model->devices = detail::devices_from_env();
-    detail::read_env(model->shift_offset, model->max_batch);
+        model->devices = devices_from_env();
+    read_env(model->shift_offset, model->max_batch);
     const char *files[1] = {model_file.c_str()};
     if (dmx_engine_create(files, 1, model->devices.data(), (int)model->devices.size(), model->max_batch, DMX_TRANSPORT_AUTO,
                           &model->engine) != DMX_OK)
     {
-        std::cerr << "load_demucs_model: " << dmx_last_error() << std::endl;
+        std::cerr << who << ": " << dmx_last_error() << std::endl;
         return false;
     }
+    if (dmx_engine_arch(model->engine) != arch)
+    {
+        std::cerr << who << ": invalid model data (bad magic)" << std::endl;
+        dmx_engine_free(model->engine);
+        model->engine = nullptr;
+        return false;
+    }
+    return true;
+}
+} // namespace detail
+inline bool load_demucs_model(const std::string &model_file, demucs_model *model)
+{
+    if (!detail::load_engine("load_demucs_model", model_file, model, 4))
+        return false;
     model->is_4sources = dmx_engine_n_sources(model->engine) == 4;
     return true;
 }
@@ -234,16 +259,23 @@ inline StemTensor demucs_ft_inference(const demucs_ft_bag &bag, const StereoMatr
 
 // segment-level surface; src/model.hpp:569-647 (only the boundary members are kept:
 // `mix` in, `targets_out` out - every intermediate lives in the HBM arena)
-struct demucs_segment_buffers
+// Under DEMUCSCPP_HIP_WITH_EIGEN the reference's name `demucs_segment_buffers` IS the Eigen-typed struct further
+// down (a caller that keeps `demucscpp::demucs_segment_buffers buffers(2, n, S); buffers.mix(i, j) = ...` with Eigen
+// semantics, src/model.hpp:569-647, must get Eigen members); this container-typed one is then reachable as
+// demucs_segment_buffers_plain only.
+struct demucs_segment_buffers_plain
 {
     int segment_samples;
     StereoMatrix mix;
     StemTensor targets_out;
-    demucs_segment_buffers(int /*nb_channels*/, int segment_samples_, int nb_sources)
+    demucs_segment_buffers_plain(int /*nb_channels*/, int segment_samples_, int nb_sources)
         : segment_samples(segment_samples_), mix(segment_samples_), targets_out(nb_sources, segment_samples_)
     {
     }
 };
+#ifndef DEMUCSCPP_HIP_WITH_EIGEN
+typedef demucs_segment_buffers_plain demucs_segment_buffers;
+#endif
 struct stft_buffers // kept for signature compatibility (src/dsp.hpp:20-101); the STFT state lives on the GPU
 {
     explicit stft_buffers(int /*n_samples*/) {}
@@ -251,7 +283,7 @@ struct stft_buffers // kept for signature compatibility (src/dsp.hpp:20-101); th
 
 namespace detail
 {
-inline void segment_call(const demucs_model &model, int segment_samples, const float *mix, float *targets_out, const ProgressCallback &cb,
+inline void segment_call(const engine_model &model, int segment_samples, const float *mix, float *targets_out, const ProgressCallback &cb,
                          float current_progress, float segment_progress)
 {
     if (segment_samples != DMX_SEGMENT_SAMPLES)
@@ -273,7 +305,7 @@ inline void segment_call(const demucs_model &model, int segment_samples, const f
 } // namespace detail
 
 // src/model.hpp:662-666, src/model_inference.cpp:48-475
-inline void model_inference(const demucs_model &model, demucs_segment_buffers &buffers, stft_buffers & /*stft_buf*/,
+inline void model_inference(const demucs_model &model, demucs_segment_buffers_plain &buffers, stft_buffers & /*stft_buf*/,
                             ProgressCallback cb, float current_progress, float segment_progress)
 {
     detail::segment_call(model, buffers.segment_samples, buffers.mix.data.data(), buffers.targets_out.data.data(), cb, current_progress,
@@ -299,19 +331,20 @@ inline Tensor3dXf demucs_inference(const demucs_model &model, const Eigen::Matri
 
 // src/model.hpp:569-647: the boundary members with the reference's names and types. The reference's
 // intermediates (x, xt, saved_*, ... :583-647) live in the HBM arena and have no host image.
-struct demucs_segment_buffers_eigen
+struct demucs_segment_buffers // the reference's name and member types
 {
     int segment_samples;
     Eigen::MatrixXf mix;     // (nb_channels, segment_samples)
     Tensor3dXf targets_out;  // (nb_sources, nb_channels, segment_samples)
-    demucs_segment_buffers_eigen(int nb_channels, int segment_samples_, int nb_sources)
+    demucs_segment_buffers(int nb_channels, int segment_samples_, int nb_sources)
         : segment_samples(segment_samples_), mix(nb_channels, segment_samples_), targets_out(nb_sources, nb_channels, segment_samples_)
     {
         mix.setZero();
         targets_out.setZero();
     }
 };
-inline void model_inference(const demucs_model &model, demucs_segment_buffers_eigen &buffers, stft_buffers & /*stft_buf*/,
+typedef demucs_segment_buffers demucs_segment_buffers_eigen; // round-2 name
+inline void model_inference(const demucs_model &model, demucs_segment_buffers &buffers, stft_buffers & /*stft_buf*/,
                             ProgressCallback cb, float current_progress, float segment_progress)
 {
     detail::segment_call(model, buffers.segment_samples, buffers.mix.data(), buffers.targets_out.data(), cb, current_progress,
@@ -320,3 +353,70 @@ inline void model_inference(const demucs_model &model, demucs_segment_buffers_ei
 #endif
 
 } // namespace demucscpp
+
+// ---------------------------------------------------------------------------------------------
+// Demucs v3 (hdemucs_mmi): /root/reference/src/model.hpp:668-1415, cli-apps/demucs_v3.cpp. Same engine, same
+// threading contract; the weight file carries the "dmc3" magic (README.md:82 ggml-model-hdemucs_mmi-v3-f16.bin).
+namespace demucscpp_v3
+{
+using demucscpp::ProgressCallback;
+using demucscpp::StemTensor;
+using demucscpp::StereoMatrix;
+
+struct demucs_v3_model : demucscpp::engine_model // src/model.hpp:694-1236: the weights live in HBM
+{
+};
+
+// src/model.hpp:1396-1397, src/model_load.cpp:1302-2166
+inline bool load_demucs_v3_model(const std::string &model_file, demucs_v3_model *model)
+{
+    return demucscpp::detail::load_engine("load_demucs_v3_model", model_file, model, 3);
+}
+
+// src/model.hpp:1405-1408, src/model_apply.cpp:307-339
+inline StemTensor demucs_v3_inference(const demucs_v3_model &model, const StereoMatrix &full_audio, ProgressCallback cb)
+{
+    StemTensor out(4, full_audio.cols());
+    demucscpp::detail::CbThunk th{&cb};
+    std::lock_guard<std::mutex> guard(model.lock);
+    if (dmx_engine_track_infer(model.engine, full_audio.data.data(), full_audio.cols(), &model.shift_offset, out.data.data(),
+                               DMX_LAYOUT_EIGEN, demucscpp::detail::progress_thunk, &th) != DMX_OK)
+        demucscpp::detail::die("demucs_v3_inference");
+    return out;
+}
+
+// src/model.hpp:1238-1394: the boundary members (`mix` in, `targets_out` out); LSTM state, decay tables and every
+// intermediate live in the HBM arena
+typedef demucscpp::demucs_segment_buffers_plain demucs_v3_segment_buffers_plain;
+#ifndef DEMUCSCPP_HIP_WITH_EIGEN
+typedef demucscpp::demucs_segment_buffers_plain demucs_v3_segment_buffers;
+#endif
+
+// src/model.hpp:1410-1414, src/model_inference.cpp:477-856
+inline void model_v3_inference(const demucs_v3_model &model, demucs_v3_segment_buffers_plain &buffers, demucscpp::stft_buffers & /*stft_buf*/,
+                               ProgressCallback cb, float current_progress, float segment_progress)
+{
+    demucscpp::detail::segment_call(model, buffers.segment_samples, buffers.mix.data.data(), buffers.targets_out.data.data(), cb,
+                                    current_progress, segment_progress);
+}
+
+#ifdef DEMUCSCPP_HIP_WITH_EIGEN
+inline demucscpp::Tensor3dXf demucs_v3_inference(const demucs_v3_model &model, const Eigen::MatrixXf &full_audio, ProgressCallback cb)
+{
+    demucscpp::Tensor3dXf out(4, 2, full_audio.cols());
+    demucscpp::detail::CbThunk th{&cb};
+    std::lock_guard<std::mutex> guard(model.lock);
+    if (dmx_engine_track_infer(model.engine, full_audio.data(), full_audio.cols(), &model.shift_offset, out.data(), DMX_LAYOUT_EIGEN,
+                               demucscpp::detail::progress_thunk, &th) != DMX_OK)
+        demucscpp::detail::die("demucs_v3_inference");
+    return out;
+}
+typedef demucscpp::demucs_segment_buffers demucs_v3_segment_buffers; // Eigen-typed mix / targets_out
+inline void model_v3_inference(const demucs_v3_model &model, demucs_v3_segment_buffers &buffers, demucscpp::stft_buffers & /*stft_buf*/,
+                               ProgressCallback cb, float current_progress, float segment_progress)
+{
+    demucscpp::detail::segment_call(model, buffers.segment_samples, buffers.mix.data(), buffers.targets_out.data(), cb, current_progress,
+                                    segment_progress);
+}
+#endif
+} // namespace demucscpp_v3

@@ -137,3 +137,22 @@ inline demucscpp::StemTensor threaded_inference(const demucscpp::demucs_model &m
     });
 }
 } // namespace demucscppthreaded
+
+// cli-apps/threaded_inference.hpp:196-369: the same split / cross-fade around demucscpp_v3::demucs_v3_inference
+namespace demucscppthreaded_v3
+{
+inline demucscpp::StemTensor threaded_inference(const demucscpp_v3::demucs_v3_model &model, const demucscpp::StereoMatrix &full_audio,
+                                                int num_threads, const std::string &prefix = "")
+{
+    if (num_threads < 1)
+        num_threads = 1;
+    std::cout << std::fixed << std::setprecision(3);
+    return demucscppthreaded::threaded_split_apply(full_audio, num_threads, 4, [&](int i, const demucscpp::StereoMatrix &chunk) {
+        demucscpp::ProgressCallback cb = [i, prefix](float progress, const std::string &log_message) {
+            std::cout << prefix << "[THREAD " << i << "] (" << std::setw(3) << std::setfill(' ') << progress * 100.0f << "%) "
+                      << log_message << std::endl;
+        };
+        return demucscpp_v3::demucs_v3_inference(model, chunk, cb);
+    });
+}
+} // namespace demucscppthreaded_v3

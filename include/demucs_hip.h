@@ -155,6 +155,7 @@ extern "C"
     int dmx_engine_n_devices(const dmx_engine *e);
     int dmx_engine_n_models(const dmx_engine *e);
     int dmx_engine_n_sources(const dmx_engine *e);
+    int dmx_engine_arch(const dmx_engine *e); /* dmx_model_arch of its models */
     int dmx_engine_transport(const dmx_engine *e);
     /* where a track is finished (overlap-add, de-normalisation, copy-out). Same bits either way.
      *   DMX_FINISH_ROOT  (default): every device's segment blocks are gathered on the first device, which

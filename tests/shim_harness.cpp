@@ -91,8 +91,8 @@ int main(int argc, char **argv)
                         printf("MISMATCH track\n");
                         return 1;
                     }
-        demucs_segment_buffers b1(2, DMX_SEGMENT_SAMPLES, 4);
-        demucs_segment_buffers_eigen b2(2, DMX_SEGMENT_SAMPLES, 4);
+        demucs_segment_buffers_plain b1(2, DMX_SEGMENT_SAMPLES, 4);
+        demucs_segment_buffers b2(2, DMX_SEGMENT_SAMPLES, 4); // the reference name: Eigen-typed under the macro (src/model.hpp:569-647)
         StereoMatrix sg = noise(DMX_SEGMENT_SAMPLES, 9);
         b1.mix = sg;
         for (int64_t i = 0; i < DMX_SEGMENT_SAMPLES; ++i)

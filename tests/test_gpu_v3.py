@@ -126,3 +126,80 @@ def test_v3_dc_stress_weights(dmx, tmp_path, oracle_threads):
     assert not bad, bad
     assert errs["out"] < TOL, errs["out"]
     ctx.close(); m.close(); om.close()
+
+
+def test_v3_cli_drop_in_vs_library_and_oracle(dmx, tmp_models, golden_dir, tmp_path, oracle_threads):
+    """cli/demucs_v3.cpp.main keeps the reference's argv contract and output naming
+    (/root/reference/cli-apps/demucs_v3.cpp:108-232); its stems equal the library's bit for bit and the ORACLE's
+    demucs_v3_inference restatement within the tolerance, on the reference's own fixture (test/data/gspi_stereo_short.wav)."""
+    import subprocess
+    from wavio import read_wav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cli", "demucs_v3.cpp.main")
+    assert os.path.exists(exe), "CLI not built"
+    wav = os.path.join(golden_dir, "gspi_stereo_short.wav")
+    out_dir = tmp_path / "stems"
+    env = dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2")
+    r = subprocess.run([exe, tmp_models[3], wav, str(out_dir)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "demucs_model_load returned true" in r.stdout and "Starting Demucs v3 MMI inference" in r.stdout
+    _, audio = read_wav(wav)
+    m = dmx.Model(tmp_models[3]); ctx = dmx.Context(m, 0, 2); om = orc.OracleModel(tmp_models[3])
+    lib = ctx.track(audio, 1337)
+    ref = om.track(audio, 1337)
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        rate, stem = read_wav(str(out_dir / f"target_{i}_{name}.wav"))
+        assert rate == 44100 and stem.shape == audio.shape
+        assert np.array_equal(stem, lib[i])
+        assert pu.relerr(stem, ref[i]) < TOL and sdr_db(ref[i], stem) > 60.0
+    # wrong usage, unreadable model, and a v4 file ("bad magic" for load_demucs_v3_model) exit 1 like the reference
+    assert subprocess.run([exe], capture_output=True).returncode == 1
+    assert subprocess.run([exe, "/nonexistent.bin", wav, str(out_dir)], capture_output=True).returncode == 1
+    r = subprocess.run([exe, tmp_models[4], wav, str(out_dir)], capture_output=True, text=True)
+    assert r.returncode == 1 and "bad magic" in r.stderr
+    # and the v4 CLI refuses the v3 file the same way
+    r = subprocess.run([os.path.join(root, "cli", "demucs.cpp.main"), tmp_models[3], wav, str(out_dir)], capture_output=True, text=True)
+    assert r.returncode == 1 and "bad magic" in r.stderr
+    ctx.close(); m.close(); om.close()
+
+
+def test_v3_cli_mt_and_sharded_devices(dmx, tmp_models, tmp_path):
+    """demucs_v3_mt.cpp.main (/root/reference/cli-apps/demucs_v3_mt.cpp:108-227): <num threads> coarse chunks recombined as
+    oracle/threaded_split.py restates cli-apps/threaded_inference.hpp:196-369; and the v3 CLI sharded over two logical
+    devices (DMX_DEVICES=0,0) gives the one-device bits."""
+    import subprocess
+    import sys
+    from wavio import read_wav, write_wav_f32
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    from threaded_split import threaded_split
+    exe, exe_mt = os.path.join(root, "cli", "demucs_v3.cpp.main"), os.path.join(root, "cli", "demucs_v3_mt.cpp.main")
+    assert os.path.exists(exe) and os.path.exists(exe_mt), "CLIs not built"
+    audio = (0.1 * np.random.default_rng(23).standard_normal((2, 4 * 44100))).astype(np.float32)
+    wav = str(tmp_path / "noise4s.wav")
+    write_wav_f32(wav, audio)
+    env = dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2")
+    names = ["drums", "bass", "other", "vocals"]
+    r = subprocess.run([exe_mt, tmp_models[3], wav, str(tmp_path / "mt"), "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "[THREAD 1]" in r.stdout
+    m = dmx.Model(tmp_models[3]); ctx = dmx.Context(m, 0, 2)
+    ref = threaded_split(audio, 2, 4, lambda i, chunk: ctx.track(chunk, 1337))
+    for i, name in enumerate(names):
+        _, stem = read_wav(str(tmp_path / "mt" / f"target_{i}_{name}.wav"))
+        assert stem.shape == audio.shape and np.abs(stem - ref[i]).max() <= 2e-6 * max(1.0, np.abs(ref[i]).max())
+    assert subprocess.run([exe_mt, tmp_models[3], wav, str(tmp_path / "mt")], capture_output=True).returncode == 1
+    ctx.close(); m.close()
+    # two segments' worth of audio dealt over two logical devices
+    n = 257985 + 5000
+    audio2 = (0.1 * np.random.default_rng(24).standard_normal((2, n))).astype(np.float32)
+    wav2 = str(tmp_path / "two.wav")
+    write_wav_f32(wav2, audio2)
+    outs = []
+    for devs in ("0", "0,0"):
+        od = tmp_path / ("dev" + devs.replace(",", "_"))
+        r = subprocess.run([exe, tmp_models[3], wav2, str(od)], env=dict(env, DMX_DEVICES=devs), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append([read_wav(str(od / f"target_{i}_{nm}.wav"))[1] for i, nm in enumerate(names)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
