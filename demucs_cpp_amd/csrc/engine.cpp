@@ -120,6 +120,9 @@ struct EngineDev
 struct dmx_engine
 {
     int nModels = 0, S = 0, maxBatch = 0, transport = DMX_TRANSPORT_P2P, finish = DMX_FINISH_ROOT;
+    bool rcclSelf = false;      // test hook DMX_RCCL_SELF=1: several logical devices on ONE GPU exchange their slabs through
+                                // ncclSend / ncclRecv to self on a 1-rank communicator (posted by the root worker)
+    hipEvent_t evExchange = nullptr; // rcclSelf + OWNER: the self exchange has been enqueued on the root's stream
     i64 seg = 0;
     std::vector<EngineDev> devs;
     std::vector<DevBuf> segOut; // root: per model [n_seg][S][2][seg]
@@ -132,7 +135,7 @@ struct dmx_engine
         for (EngineDev &d : devs)
         {
             (void)hipSetDevice(d.dev);
-            if (d.comm && api && api->CommDestroy)
+            if (d.comm && api && api->CommDestroy && (!rcclSelf || &d == &devs[0]))
                 (void)api->CommDestroy(d.comm);
             if (d.evDone)
                 (void)hipEventDestroy(d.evDone);
@@ -148,6 +151,8 @@ struct dmx_engine
         if (!devs.empty())
         {
             (void)hipSetDevice(devs[0].dev);
+            if (evExchange)
+                (void)hipEventDestroy(evExchange);
             for (DevBuf &b : segOut)
                 if (b.p)
                     (void)hipFree(b.p);
@@ -212,7 +217,18 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
     if (transport != DMX_TRANSPORT_P2P && transport != DMX_TRANSPORT_RCCL)
         return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: unknown transport %d", transport);
     if (transport == DMX_TRANSPORT_RCCL && !distinct)
-        return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the RCCL transport needs distinct devices (a communicator holds a GPU once)");
+    {
+        // Test hook for 1-GPU boxes: all logical devices on ONE GPU, one 1-rank communicator; every slab / tail travels
+        // through ncclSend + ncclRecv to self, so the RCCL data path (argument order, counts, offsets, stream ordering)
+        // is executed on hardware even where no second GPU exists.
+        bool same = true;
+        for (int v : devs)
+            same = same && v == devs[0];
+        const char *self = getenv("DMX_RCCL_SELF");
+        if (!(self && !strcmp(self, "1") && same))
+            return dmx_fail(DMX_ERR_ARG, "dmx_engine_create: the RCCL transport needs distinct devices (a communicator holds a GPU once)");
+        e->rcclSelf = true;
+    }
     e->transport = transport;
     e->devs.resize(devs.size());
     for (size_t l = 0; l < devs.size(); ++l)
@@ -274,10 +290,22 @@ extern "C" int dmx_engine_create(const char *const *model_files, int n_models, c
         RcclApi *api = rccl_api();
         if (!api->handle || !api->why.empty())
             return dmx_fail(DMX_ERR_HIP, "dmx_engine_create: RCCL transport unavailable (%s); DMX_GATHER=p2p selects peer copies", api->why.c_str());
-        std::vector<ncclComm_t> comms(devs.size(), nullptr);
-        NCCLCHK(api->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
-        for (size_t l = 0; l < devs.size(); ++l)
-            e->devs[l].comm = comms[l];
+        if (e->rcclSelf)
+        {
+            ncclComm_t comm = nullptr;
+            NCCLCHK(api->CommInitAll(&comm, 1, devs.data()));
+            for (size_t l = 0; l < devs.size(); ++l)
+                e->devs[l].comm = comm;
+            HIPCHK(hipSetDevice(devs[0]));
+            HIPCHK(hipEventCreateWithFlags(&e->evExchange, hipEventDisableTiming));
+        }
+        else
+        {
+            std::vector<ncclComm_t> comms(devs.size(), nullptr);
+            NCCLCHK(api->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+            for (size_t l = 0; l < devs.size(); ++l)
+                e->devs[l].comm = comms[l];
+        }
     }
     *out = e.release();
     return DMX_OK;
@@ -302,6 +330,9 @@ extern "C" dmx_ctx *dmx_engine_root_ctx(dmx_engine *e, int model)
 {
     if (!e || model < 0 || model >= e->nModels)
         return nullptr;
+    // the rebind is ordered against a running dmx_engine_track_infer; the CALLS the caller then makes on the returned
+    // context are not: a context is single-threaded (include/demucs_hip.h), the C++ shim serialises them with the model lock
+    std::lock_guard<std::mutex> guard(e->mu);
     if (dmx_ctx_set_model(e->devs[0].ctx, e->devs[0].models[(size_t)model]) != DMX_OK)
         return nullptr;
     return e->devs[0].ctx;
@@ -328,8 +359,32 @@ struct Shared
     // OWNER finish mode, peer-copy transport: haloReady[l][ri] is set by the sender once its copy has landed
     std::vector<std::vector<char>> haloReady;
     bool failed = false; // a worker gave up: receivers stop waiting
+    int arrived[2] = {0, 0}; // host barriers of the RCCL transports (agree())
 };
 } // namespace
+
+// test hook: DMX_TEST_FAIL_DEV=<logical device> makes that device's compute phase fail (the exchange must then be
+// skipped by everybody instead of hanging: tests/test_gpu_parity.py)
+static bool fault_injected(int l)
+{
+    const char *v = getenv("DMX_TEST_FAIL_DEV");
+    return v && *v && atoi(v) == l;
+}
+
+// Host barrier of the RCCL transports. A collective-style exchange deadlocks when one participant never posts its
+// half (its peers sit in hipStreamSynchronize behind an unmatched ncclRecv / ncclSend), so the workers first AGREE
+// that every one of them got through its compute phase: each arrives exactly once per barrier `which` with its own
+// status; the call returns true only if all G arrived healthy. Nobody posts an RCCL call otherwise.
+static bool agree(Shared &sh, int which, int G, bool ok)
+{
+    std::unique_lock<std::mutex> lk(sh.mu);
+    if (!ok)
+        sh.failed = true;
+    ++sh.arrived[which];
+    sh.cv.notify_all();
+    sh.cv.wait(lk, [&] { return sh.arrived[which] >= G; });
+    return !sh.failed;
+}
 
 // items of model m: first global item index
 static void partition(const std::vector<int> &nseg, int G, std::vector<std::vector<Run>> &runs)
@@ -408,35 +463,79 @@ static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64
     dmx_ctx *c = d.ctx;
     const int S = e->S;
     const i64 seg = e->seg, blk = (i64)S * 2 * seg;
-    HIPCHK(hipSetDevice(d.dev));
-    if (!runs.empty() || l == 0)
-    {
-        DMXCHK(upload_track(c, audio, layout, n));
-    }
     std::vector<int> idx;
     size_t nev = 0;
     std::vector<int> evItems;
-    for (const Run &r : runs)
-    {
-        DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
-        float *dst = l == 0 ? e->segOut[(size_t)r.model].p + (i64)r.g0 * blk : d.slab.p + r.slabOff * blk;
-        for (int g = r.g0; g < r.g1; g += e->maxBatch)
+    const bool rccl = e->transport == DMX_TRANSPORT_RCCL && e->devs.size() > 1;
+    auto compute = [&]() -> int {
+        HIPCHK(hipSetDevice(d.dev));
+        if (fault_injected(l))
+            return dmx_fail(DMX_ERR_HIP, "device %d: injected fault (DMX_TEST_FAIL_DEV)", l);
+        if (!runs.empty() || l == 0)
         {
-            const int nb = std::min(e->maxBatch, r.g1 - g);
-            idx.resize((size_t)nb);
-            for (int i = 0; i < nb; ++i)
-                idx[(size_t)i] = g + i;
-            DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
-            DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
-            hipEvent_t ev = dmx_batch_event(c, nev++);
-            if (!ev)
-                return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
-            HIPCHK(hipEventRecord(ev, c->stream));
-            evItems.push_back(nb);
+            DMXCHK(upload_track(c, audio, layout, n));
+        }
+        for (const Run &r : runs)
+        {
+            DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
+            float *dst = l == 0 ? e->segOut[(size_t)r.model].p + (i64)r.g0 * blk : d.slab.p + r.slabOff * blk;
+            for (int g = r.g0; g < r.g1; g += e->maxBatch)
+            {
+                const int nb = std::min(e->maxBatch, r.g1 - g);
+                idx.resize((size_t)nb);
+                for (int i = 0; i < nb; ++i)
+                    idx[(size_t)i] = g + i;
+                DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
+                DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
+                hipEvent_t ev = dmx_batch_event(c, nev++);
+                if (!ev)
+                    return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
+                HIPCHK(hipEventRecord(ev, c->stream));
+                evItems.push_back(nb);
+            }
+        }
+        if (e->rcclSelf)
+            HIPCHK(hipEventRecord(d.evDone, c->stream)); // the root's stream waits for it before the self exchange
+        return DMX_OK;
+    };
+    const int crc = compute();
+    if (rccl)
+    {
+        // no worker posts an RCCL call unless every worker got here healthy (a missing partner would hang the rest)
+        const std::string cerr = crc == DMX_OK ? std::string() : dmx_err_string();
+        if (!agree(sh, 0, (int)e->devs.size(), crc == DMX_OK))
+        {
+            if (crc != DMX_OK)
+            {
+                dmx_set_err_string(cerr);
+                return crc;
+            }
+            return dmx_fail(DMX_ERR_HIP, "device %d: another device failed before the exchange; no RCCL call was posted", l);
         }
     }
+    else if (crc != DMX_OK)
+        return crc;
     // ---- the exchange step
-    if (e->transport == DMX_TRANSPORT_RCCL && e->devs.size() > 1)
+    if (rccl && e->rcclSelf)
+    {
+        // one GPU, one 1-rank communicator: the root posts every slab as ncclSend + ncclRecv to self in ONE group
+        RcclApi *api = rccl_api();
+        if (l == 0)
+        {
+            for (size_t p = 1; p < allRuns.size(); ++p)
+                HIPCHK(hipStreamWaitEvent(c->stream, e->devs[p].evDone, 0));
+            NCCLCHK(api->GroupStart());
+            for (size_t p = 1; p < allRuns.size(); ++p)
+                for (const Run &r : allRuns[p])
+                {
+                    const size_t cnt = (size_t)((i64)(r.g1 - r.g0) * blk);
+                    NCCLCHK(api->Send(e->devs[p].slab.p + r.slabOff * blk, cnt, kNcclFloat, 0, d.comm, c->stream));
+                    NCCLCHK(api->Recv(e->segOut[(size_t)r.model].p + (i64)r.g0 * blk, cnt, kNcclFloat, 0, d.comm, c->stream));
+                }
+            NCCLCHK(api->GroupEnd());
+        }
+    }
+    else if (rccl)
     {
         RcclApi *api = rccl_api();
         if (l != 0)
@@ -484,39 +583,113 @@ static int device_work_owner(dmx_engine *e, int l, const float *audio, int layou
     const std::vector<Run> &runs = allRuns[(size_t)l];
     const int S = e->S, M = e->nModels;
     const i64 seg = e->seg, blk = (i64)S * 2 * seg, tail = seg - stride, halo = (i64)S * 2 * tail;
-    if (runs.empty())
-        return DMX_OK;
-    HIPCHK(hipSetDevice(d.dev));
-    DMXCHK(upload_track(c, audio, layout, n));
+    const bool rccl = e->transport == DMX_TRANSPORT_RCCL;
+    const int G = (int)e->devs.size();
     std::vector<int> idx, evItems;
     size_t nev = 0;
-    for (const Run &r : runs)
-    {
-        DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
-        float *dst = d.slab.p + r.ownSlot * blk;
-        for (int g = r.g0; g < r.g1; g += e->maxBatch)
+    // compute phase + packing of the tails [stride, seg) of the boundary segments (S*2 rows of `tail` floats)
+    auto compute = [&]() -> int {
+        if (fault_injected(l))
+            return dmx_fail(DMX_ERR_HIP, "device %d: injected fault (DMX_TEST_FAIL_DEV)", l);
+        if (runs.empty())
+            return DMX_OK;
+        HIPCHK(hipSetDevice(d.dev));
+        DMXCHK(upload_track(c, audio, layout, n));
+        for (const Run &r : runs)
         {
-            const int nb = std::min(e->maxBatch, r.g1 - g);
-            idx.resize((size_t)nb);
-            for (int i = 0; i < nb; ++i)
-                idx[(size_t)i] = g + i;
-            DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
-            DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
-            hipEvent_t ev = dmx_batch_event(c, nev++);
-            if (!ev)
-                return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
-            HIPCHK(hipEventRecord(ev, c->stream));
-            evItems.push_back(nb);
+            DMXCHK(dmx_ctx_set_model(c, d.models[(size_t)r.model]));
+            float *dst = d.slab.p + r.ownSlot * blk;
+            for (int g = r.g0; g < r.g1; g += e->maxBatch)
+            {
+                const int nb = std::min(e->maxBatch, r.g1 - g);
+                idx.resize((size_t)nb);
+                for (int i = 0; i < nb; ++i)
+                    idx[(size_t)i] = g + i;
+                DMXCHK(dmx_track_gather_device(c, c->bAudio.p, n, c->dStats, shifts[(size_t)r.model], idx.data(), nb, c->bMix.p));
+                DMXCHK(dmx_segment_infer_device(c, c->bMix.p, dst + (i64)(g - r.g0) * blk, nb));
+                hipEvent_t ev = dmx_batch_event(c, nev++);
+                if (!ev)
+                    return dmx_fail(DMX_ERR_HIP, "hipEventCreate failed");
+                HIPCHK(hipEventRecord(ev, c->stream));
+                evItems.push_back(nb);
+            }
+        }
+        for (size_t ri = 0; ri < runs.size(); ++ri)
+            if (runs[ri].succDev >= 0)
+                launch_copy_rows(d.haloSend.p + (i64)ri * halo, tail, d.slab.p + (runs[ri].ownSlot + (runs[ri].g1 - 1 - runs[ri].g0)) * blk + stride,
+                                 seg, tail, S * 2, c->stream);
+        HIPCHK(hipGetLastError());
+        if (e->rcclSelf)
+            HIPCHK(hipEventRecord(d.evDone, c->stream));
+        return DMX_OK;
+    };
+    const int crc = compute();
+    if (rccl)
+    {
+        // every worker (also one without items) arrives: nobody posts an RCCL call unless all are healthy
+        const std::string cerr = crc == DMX_OK ? std::string() : dmx_err_string();
+        if (!agree(sh, 0, G, crc == DMX_OK))
+        {
+            if (crc != DMX_OK)
+            {
+                dmx_set_err_string(cerr);
+                return crc;
+            }
+            return dmx_fail(DMX_ERR_HIP, "device %d: another device failed before the exchange; no RCCL call was posted", l);
         }
     }
-    // ---- the exchange step: tails [stride, seg) of the boundary segments, packed to S*2 rows of `tail` floats
-    const bool rccl = e->transport == DMX_TRANSPORT_RCCL;
-    for (size_t ri = 0; ri < runs.size(); ++ri)
-        if (runs[ri].succDev >= 0)
-            launch_copy_rows(d.haloSend.p + (i64)ri * halo, tail, d.slab.p + (runs[ri].ownSlot + (runs[ri].g1 - 1 - runs[ri].g0)) * blk + stride,
-                             seg, tail, S * 2, c->stream);
-    HIPCHK(hipGetLastError());
-    if (rccl)
+    else if (crc != DMX_OK)
+        return crc;
+    if (rccl && e->rcclSelf)
+    {
+        // one GPU, one 1-rank communicator: the root posts every tail as ncclSend + ncclRecv to self in ONE group on
+        // its stream, then every worker orders its own stream behind that exchange
+        RcclApi *api = rccl_api();
+        int xrc = DMX_OK;
+        std::string xerr;
+        if (l == 0)
+        {
+            auto post = [&]() -> int {
+                dmx_ctx *c0 = e->devs[0].ctx;
+                HIPCHK(hipSetDevice(e->devs[0].dev));
+                for (int q = 0; q < G; ++q)
+                    if (!allRuns[(size_t)q].empty())
+                        HIPCHK(hipStreamWaitEvent(c0->stream, e->devs[(size_t)q].evDone, 0));
+                NCCLCHK(api->GroupStart());
+                for (int q = 0; q < G; ++q)
+                    for (size_t ri = 0; ri < allRuns[(size_t)q].size(); ++ri)
+                    {
+                        const Run &r = allRuns[(size_t)q][ri];
+                        if (r.succDev < 0)
+                            continue;
+                        EngineDev &dst = e->devs[(size_t)r.succDev];
+                        NCCLCHK(api->Send(e->devs[(size_t)q].haloSend.p + (i64)ri * halo, (size_t)halo, kNcclFloat, 0, d.comm, c0->stream));
+                        NCCLCHK(api->Recv(dst.haloRecv.p + (i64)r.succRun * halo, (size_t)halo, kNcclFloat, 0, d.comm, c0->stream));
+                    }
+                NCCLCHK(api->GroupEnd());
+                HIPCHK(hipEventRecord(e->evExchange, c0->stream));
+                return DMX_OK;
+            };
+            xrc = post();
+            if (xrc != DMX_OK)
+                xerr = dmx_err_string();
+        }
+        if (!agree(sh, 1, G, xrc == DMX_OK)) // the exchange event exists (recorded) before anyone waits on it
+        {
+            if (xrc != DMX_OK)
+            {
+                dmx_set_err_string(xerr);
+                return xrc;
+            }
+            return dmx_fail(DMX_ERR_HIP, "device %d: the self exchange could not be posted", l);
+        }
+        if (runs.empty())
+            return DMX_OK;
+        HIPCHK(hipStreamWaitEvent(c->stream, e->evExchange, 0));
+    }
+    else if (runs.empty())
+        return DMX_OK;
+    else if (rccl)
     {
         RcclApi *api = rccl_api();
         NCCLCHK(api->GroupStart());

@@ -510,14 +510,72 @@ def test_engine_owner_finish_mode_equals_root_gather_bitwise(dmx, tmp_models, tm
 def test_engine_rccl_transport_binds_and_builds_a_communicator(dmx, tmp_models):
     """The RCCL transport (ncclCommInitAll / ncclSend / grouped ncclRecv, bound with dlopen) on the one GPU of
     this box: the library loads, every symbol resolves, a communicator is built and destroyed, and a bag run
-    goes through the RCCL code path's scheduling (with one device there is no peer to exchange with; the
-    exchange itself needs >= 2 GPUs and is covered by bench.py --gpus N under the driver). Duplicate devices
-    must be refused for RCCL."""
+    goes through the RCCL code path's scheduling (with one device there is no peer to exchange with; the exchange
+    itself is run on this box by test_engine_rccl_self_exchange_moves_the_slabs). Duplicate devices must be refused
+    for RCCL unless the DMX_RCCL_SELF test hook is set."""
     eng = dmx.Engine([tmp_models[4]], [0], max_batch=1, transport=dmx.TRANSPORT_RCCL)
     assert eng.transport == dmx.TRANSPORT_RCCL
     eng.close()
     with pytest.raises(dmx.DmxError):
         dmx.Engine([tmp_models[4]], [0, 0], max_batch=1, transport=dmx.TRANSPORT_RCCL)
+
+
+def test_engine_rccl_self_exchange_moves_the_slabs(dmx, tmp_models, monkeypatch):
+    """The RCCL DATA path on the one GPU of this box: with DMX_RCCL_SELF=1 several logical devices
+    share a 1-rank communicator and every slab (ROOT finish) / segment tail (OWNER finish) travels through a grouped
+    ncclSend + ncclRecv to self - same buffers, counts, offsets and stream ordering as the multi-GPU exchange - and the
+    result must equal the single-context bits. Includes the 6-source model (configs[3]) and the fine-tuned bag (configs[4])."""
+    monkeypatch.setenv("DMX_RCCL_SELF", "1")
+    stride = 257985
+    n = 4 * stride + 1000  # 5 segments
+    audio = (0.1 * np.random.default_rng(43).standard_normal((2, n)) + 0.02).astype(np.float32)
+    m = dmx.Model(tmp_models[6]); ctx = dmx.Context(m, 0, 2)
+    ref = ctx.track(audio, 4033)
+    ctx.close(); m.close()
+    for finish in (dmx.FINISH_ROOT, dmx.FINISH_OWNER):
+        eng = dmx.Engine([tmp_models[6]], [0, 0, 0], max_batch=2, transport=dmx.TRANSPORT_RCCL, finish=finish)
+        assert eng.transport == dmx.TRANSPORT_RCCL and eng.n_devices == 3
+        for _ in range(2):  # buffers and the communicator are reused
+            assert np.array_equal(eng.track(audio, [4033]), ref)
+        eng.close()
+    # the bag: 4 models x 2 segments dealt over 3 logical devices (a device's slab spans two models)
+    from demucs_cpp_amd.weights import write_synthetic_model
+    import tempfile
+    d = tempfile.mkdtemp()
+    files = []
+    for i, nm in enumerate(["drums", "bass", "other", "vocals"]):
+        f = os.path.join(d, f"ggml-model-htdemucs_ft_{nm}-4s-f16.bin")
+        write_synthetic_model(f, 4, 100 + i)
+        files.append(f)
+    n2 = stride + 5000
+    audio2 = (0.1 * np.random.default_rng(44).standard_normal((2, n2))).astype(np.float32)
+    shifts = list(SHIFTS_GLIBC)
+    one = dmx.Engine(files, [0], max_batch=2)
+    refb = one.track(audio2, shifts)
+    one.close()
+    eng = dmx.Engine(files, [0, 0, 0], max_batch=2, transport=dmx.TRANSPORT_RCCL)
+    assert np.array_equal(eng.track(audio2, shifts), refb)
+    eng.close()
+
+
+def test_engine_rccl_agrees_before_the_exchange(dmx, tmp_models, monkeypatch):
+    """a device that fails before posting its half of the exchange must not leave its peers blocked
+    behind an unmatched ncclRecv / ncclSend. With a fault injected into logical device 1, both finish modes return the
+    error (no RCCL call is posted by anybody) and the engine stays usable."""
+    monkeypatch.setenv("DMX_RCCL_SELF", "1")
+    stride = 257985
+    n = 2 * stride + 1000
+    audio = (0.1 * np.random.default_rng(45).standard_normal((2, n))).astype(np.float32)
+    for finish in (dmx.FINISH_ROOT, dmx.FINISH_OWNER):
+        eng = dmx.Engine([tmp_models[4]], [0, 0, 0], max_batch=1, transport=dmx.TRANSPORT_RCCL, finish=finish)
+        good = eng.track(audio, [1337])
+        monkeypatch.setenv("DMX_TEST_FAIL_DEV", "1")
+        with pytest.raises(dmx.DmxError) as e:
+            eng.track(audio, [1337])
+        assert "injected fault" in str(e.value) or "another device failed" in str(e.value)
+        monkeypatch.delenv("DMX_TEST_FAIL_DEV")
+        assert np.array_equal(eng.track(audio, [1337]), good)
+        eng.close()
 
 
 def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
