@@ -5,12 +5,15 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 as one rank per GPU by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
 environment, backend "nccl" = RCCL). Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1], batched): htdemucs-4s, synthetic dmc4 weights (seed 0),
-synthetic 44.1 kHz stereo 0.1*N(0,1), segments of 343980 samples (7.8 s), fp32 arithmetic.
-One step on every rank = `--batch` segments, already resident in HBM, through the whole hot
-path (STFT -> encoders -> cross-transformer -> decoders -> ISTFT, C ABI
-dmx_segment_infer_device). This is the embarrassingly parallel segment loop of
-src/model_apply.cpp:189-235: ranks own disjoint segments (weak scaling, no collective inside the
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): htdemucs-4s, synthetic dmc4 weights
+(seed 0), a ~4-minute synthetic 44.1 kHz stereo track 0.1*N(0,1) RESIDENT IN HBM, fp32 arithmetic. One step on every
+rank = one such track through the whole path of demucs_inference (src/model_apply.cpp:60-288) on the device entry
+points of the C ABI: track statistics (dmx_track_stats_device), extraction + normalisation + centring of its
+`--batch` = 42 overlapping segments of 343980 samples (dmx_track_gather_device), the segment graph STFT -> encoders
+-> cross-transformer -> decoders -> ISTFT on all of them (dmx_segment_infer_device), and the triangle-weighted
+overlap-add + de-normalisation (dmx_track_overlap_add_device), stems left in HBM. At N = 1 the track is literally
+configs[2]: 10 584 000 samples, shift offset 4033 -> 42 segments. The segment loop is embarrassingly parallel
+(src/model_apply.cpp:189-235): ranks own disjoint stretches of segments (weak scaling, no collective inside the
 hot path). The one real exchange step of the track path - gathering the per-segment outputs
 to the root before overlap-add (north_star) - is part of every step when N > 1
 (RCCL gather over xGMI), followed by the root's triangle-weighted overlap-add of all N*batch
@@ -21,23 +24,25 @@ segment, src/model_apply.cpp:162), which the root overlap-adds into n_track = N*
 samples; value = n_track/44100 * K / T, T = max over ranks of the barrier-bracketed wall time of the K timed
 steps. (Round 1 counted the 7.8 s every segment PROCESSES; that figure stays in config.segment_seconds_per_s.)
 
-config also reports, measured in this same run:
-  track_4min_xRT      (N = 1) BASELINE configs[2] end to end through dmx_track_infer: host buffers in and
-                      out (PCIe inclusive: H2D of the 85 MB track, normalisation, 42 segments, overlap-add,
-                      D2H of the 339 MB stems), 240 s / wall;
-  track_strong_xRT    (every N) ONE such track with its 42 segments dealt over the N ranks (contiguous
-                      ranges), RCCL gather of the per-segment outputs to the root, root overlap-add, D2H on
+config also reports, as SCALAR keys, measured in this same run:
+  track_4min_host_xRT / track_4min_host_wall_s   (N = 1) the same configs[2] track end to end through dmx_track_infer
+                      with HOST buffers in and out (PCIe inclusive: H2D of the 85 MB track, 42 segments, overlap-add,
+                      D2H of the 339 MB stems), 240 s / best wall of 3; never `value` (the boundary rule of the contract);
+  track_strong_xRT / track_strong_wall_s   (every N) ONE such track with its 42 segments dealt over the N ranks
+                      (contiguous ranges), RCCL gather of the per-segment outputs to the root, root overlap-add, D2H on
                       the root: strong scaling of a single track (<= 87.5 % at N = 8: 42 = 6+6+5*6);
   single_segment_latency_ms  BASELINE configs[1] read literally (one segment per call, device resident).
+`--model v3` runs the same workload on Demucs v3 (hdemucs_mmi, synthetic dmc3 weights): its own metric name.
 
 Extra objects on the JSON line:
   roofline     : dominant kernel (by device time) measured live with HIP events on the stream
                  it runs on (dmx_debug_profile), algorithmic FLOPs / duration vs the fp32 MFMA
                  peak 157.3 TFLOP/s (MI355X_MICROARCH.md); traffic = PMC HBM bytes (null unless
                  profiles/ holds a counter pass)
-  cpu_baseline : the CPU oracle (oracle/, a from-scratch port of the reference algorithm;
-                 the reference itself needs Eigen and cannot be built here) timed on this box's
-                 host cores on ONE full segment, rank 0 at N = 1 only.
+  cpu_baseline : the CPU oracle (oracle/, a from-scratch port of the reference algorithm; the reference itself
+                 needs Eigen and cannot be built here) timed on this box's host cores on ONE full segment, 1 warm-up +
+                 median of 3, rank 0 at N = 1 only; `openblas_*` keys: the same port with its GEMMs routed through the
+                 OpenBLAS that NumPy bundles (configs[0] names "Eigen/OpenBLAS").
 """
 import argparse
 import json
@@ -83,7 +88,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "24")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMX_BENCH_BATCH", "42")),
+                    help="segments per GPU per step; 42 = the segments of configs[2]'s 4-minute track")
+    ap.add_argument("--model", default="4s", choices=["4s", "v3"], help="4s: htdemucs (the BASELINE metric); v3: hdemucs_mmi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
@@ -123,9 +130,10 @@ def main():
 
     B = args.batch
     S = 4
+    v3 = args.model == "v3"
     tmpdir = os.environ.get("TMPDIR", "/tmp")
-    mpath = os.path.join(tmpdir, f"dmx_bench_model_4s_{os.getpid()}.bin")
-    write_synthetic_model(mpath, 4, 0)
+    mpath = os.path.join(tmpdir, f"dmx_bench_model_{args.model}_{os.getpid()}.bin")
+    write_synthetic_model(mpath, 4, 0, "default", "v3" if v3 else "v4")
     model = dmx.Model(mpath, local_rank)
     os.remove(mpath)
     ctx = dmx.Context(model, SEG, B)
@@ -138,16 +146,23 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
 
+    stride = int((1 - 0.25) * SEG)
+    nseg_total = world * B
+    # This rank's stretch of the track, interleaved stereo, resident in HBM. N = 1, batch 42: literally configs[2]
+    # (10 584 000 samples, shift 4033 -> 42 segments). Otherwise a stretch whose segment loop
+    # (`for offset < len; offset += stride`, len = n + 22050 - shift) has exactly B iterations at shift 0, and the
+    # N*B segments of a step are overlap-added by the root as ONE track of n_track samples.
+    literal = world == 1 and B == 42
+    n_rank, shift = (240 * 44100, 4033) if literal else (B * stride - 22050, 0)
+    n_track = n_rank if literal else nseg_total * stride - 22050
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    mix = (0.1 * torch.randn((B, SEG, 2), generator=gen)).cuda()  # interleaved stereo, resident in HBM
+    d_audio = (0.1 * torch.randn((n_rank, 2), generator=gen)).cuda()
+    assert ctx.track_geometry(n_rank, shift)[1] == B
+    mix = torch.zeros((B, SEG, 2), device="cuda")  # the step's segments (written by dmx_track_gather_device)
+    seg_ids = list(range(B))
     outs = [torch.zeros((B, S, 2, SEG), device="cuda") for _ in range(2)]  # double buffered: step i -> slot i & 1
     out = outs[0]
-    nseg_total = world * B
-    stride = int((1 - 0.25) * SEG)
-    # the N*B segments of one step form a stretch of a track whose segment loop
-    # (`for offset < len; offset += stride`) has exactly nseg_total iterations: len = nseg*stride
-    n_track = nseg_total * stride - 22050  # shift offset 0: len = n + 22050
-    d_stats = torch.tensor([0.0, 1.0, 0.0, 0.0], device="cuda")
+    d_stats = torch.zeros(4, device="cuda")  # mean / std of the track's mono reference (dmx_track_stats_device)
     allseg = [None, None]   # root: [world*B][S][2][SEG] per slot, rank-major; the gather lands in views of it
     gathered = [None, None]
     track_out = None
@@ -181,13 +196,15 @@ def main():
         """root: triangle-weighted overlap-add of the step held in `slot` (after its gather landed)"""
         if world > 1:
             works[slot].wait()  # stream-level: `stream` waits for the RCCL gather
-        ctx.track_overlap_add_device(allseg[slot].data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), track_out.data_ptr())
+        ctx.track_overlap_add_device(allseg[slot].data_ptr(), nseg_total, n_track, shift, d_stats.data_ptr(), track_out.data_ptr())
 
     def step(i):
         slot = i & 1
         if world > 1 and works[slot] is not None:
             works[slot].wait()  # the gather that last read outs[slot] (step i-2) is complete before it is overwritten
-        ctx.segment_device(mix.data_ptr(), outs[slot].data_ptr(), B)
+        ctx.track_stats_device(d_audio.data_ptr(), n_rank, d_stats.data_ptr())                      # model_apply.cpp:72-82
+        ctx.track_gather_device(d_audio.data_ptr(), n_rank, d_stats.data_ptr(), shift, seg_ids, mix.data_ptr())  # :93-138,189-205,250-263
+        ctx.segment_device(mix.data_ptr(), outs[slot].data_ptr(), B)                                # model_inference.cpp:48-475
         if world > 1 and test_mode:
             works[slot] = HostGather(outs[slot], gathered[slot] if rank == 0 else None)
         elif world > 1:
@@ -234,14 +251,18 @@ def main():
         if rank == 0:
             ref = torch.zeros_like(track_out)
             parts = []
-            for r in range(world):
+            st = torch.zeros(4, device="cuda")
+            for r in reversed(range(world)):  # rank 0 last: `st` ends as the root's own statistics
                 g = torch.Generator(device="cpu").manual_seed(1000 + r)
-                mr = (0.1 * torch.randn((B, SEG, 2), generator=g)).cuda()
+                ar = (0.1 * torch.randn((n_rank, 2), generator=g)).cuda()
+                mr = torch.zeros((B, SEG, 2), device="cuda")
                 o = torch.zeros((B, S, 2, SEG), device="cuda")
+                ctx.track_stats_device(ar.data_ptr(), n_rank, st.data_ptr())
+                ctx.track_gather_device(ar.data_ptr(), n_rank, st.data_ptr(), shift, seg_ids, mr.data_ptr())
                 ctx.segment_device(mr.data_ptr(), o.data_ptr(), B)
-                parts.append(o)
+                parts.insert(0, o)
             allref = torch.cat(parts, dim=0)
-            ctx.track_overlap_add_device(allref.data_ptr(), nseg_total, n_track, 0, d_stats.data_ptr(), ref.data_ptr())
+            ctx.track_overlap_add_device(allref.data_ptr(), nseg_total, n_track, shift, st.data_ptr(), ref.data_ptr())
             torch.cuda.synchronize()
             same = bool(torch.equal(ref, track_out)) and bool(torch.equal(allref, allseg[slot]))
             print(f"[test mode] world={world}: gathered slabs and overlap-added track bit-identical to a local recomputation: {same}", flush=True)
@@ -335,7 +356,7 @@ def main():
             "algorithmic_flops_per_launch": fl / cnt, "algorithmic_bytes_per_launch": by / cnt,
             "kernel_share_of_device_time": round(ms / tot_ms, 3),
             "sum_of_kernel_ms_per_step": round(tot_ms, 3),
-            "whole_path_tflops": round(MODEL_FLOPS_4S * B / (tot_ms * 1e-3) / 1e12, 2),
+            "whole_path_tflops": round((sum(v[1] for v in by_kernel.values()) if v3 else MODEL_FLOPS_4S * B) / (tot_ms * 1e-3) / 1e12, 2),
         }
 
     cpu_baseline = None
@@ -343,23 +364,40 @@ def main():
         import oracle_lib as orc  # test infrastructure, timed here only as the reported CPU baseline
 
         mpath2 = os.path.join(tmpdir, f"dmx_bench_model_cpu_{os.getpid()}.bin")
-        write_synthetic_model(mpath2, 4, 0)
+        write_synthetic_model(mpath2, 4, 0, "default", "v3" if v3 else "v4")
         om = orc.OracleModel(mpath2)
         os.remove(mpath2)
         cm = np.ascontiguousarray(mix[0].cpu().numpy().T)
-        t0 = time.perf_counter()
-        om.segment(cm)
-        dt = time.perf_counter() - t0
+
+        def timed(runs=3):  # 1 warm-up + median of >= 3
+            om.segment(cm)
+            ts = []
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                om.segment(cm)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), ts
+
+        dt, ts = timed()
         cpu_baseline = {"value": round(SEG_SECONDS / dt, 4), "unit": "audio-sec/s", "cores": int(orc.lib().orc_num_threads()),
-                        "kind": "port", "sample": f"1 full 7.8 s segment (343980 samples), htdemucs-4s synthetic weights, {dt:.1f} s wall",
+                        "kind": "port",
+                        "sample": f"1 full 7.8 s segment (343980 samples), {'hdemucs_mmi' if v3 else 'htdemucs-4s'} synthetic weights, "
+                                  f"1 warm-up + median of 3 ({dt:.1f} s; runs {', '.join(f'{t:.1f}' for t in ts)})",
                         "published_reference_context": "0.385x RT on 16 Zen3 cores, real weights (.github/PERFORMANCE.md:42-47)"}
+        blas = orc.use_openblas(True)  # configs[0] names "Eigen/OpenBLAS": the same port on NumPy's bundled OpenBLAS sgemm
+        if blas:
+            dtb, tsb = timed()
+            cpu_baseline.update({"openblas_value": round(SEG_SECONDS / dtb, 4), "openblas_kind": "port+openblas",
+                                 "openblas_sample": f"same segment, GEMMs through {os.path.basename(blas)} cblas_sgemm, median of 3 ({dtb:.1f} s)"})
+            orc.use_openblas(False)
         om.close()
 
     if rank == 0:
         audio_s = n_track / 44100.0 * args.steps          # seconds of track produced
         seg_s = nseg_total * SEG_SECONDS * args.steps        # seconds of audio processed (segments overlap by 25 %)
         line = {
-            "metric": "audio-sec/s (xRT) htdemucs-4s 44.1kHz stereo, per-segment hot path",
+            "metric": ("audio-sec/s (xRT) hdemucs_mmi (Demucs v3) 44.1kHz stereo, ~4-min track with overlap-add" if v3 else
+                       "audio-sec/s (xRT) htdemucs-4s 44.1kHz stereo, ~4-min track with overlap-add (BASELINE configs[2])"),
             "value": round(audio_s / elapsed, 2),
             "unit": "audio-sec/s",
             "n_gpus": world,
@@ -371,19 +409,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "htdemucs-4s f16-weights, 343980-sample segments, fp32 MFMA compute, "
-                                   f"{B} consecutive overlapping segments/GPU/step resident in HBM + root overlap-add"
+            "config": {"workload": ("hdemucs_mmi (v3)" if v3 else "htdemucs-4s") + " f16-weights, fp32 MFMA compute: "
+                                   + (f"configs[2] literally - one 4-minute track (10 584 000 samples, shift 4033, {B} segments of 343980) "
+                                      if literal else f"a track stretch of {B} overlapping 343980-sample segments per GPU ")
+                                   + "resident in HBM per step: statistics + segment extraction + segment graph + overlap-add"
                                    + (" + RCCL gather to root" if world > 1 else ""),
                        "value_counts": "seconds of track produced (5.85 s of new audio per 7.8 s segment, stride 257985)",
                        "segments_per_gpu_per_step": B, "segment_samples": SEG, "audio_seconds_per_segment": SEG_SECONDS,
+                       "track_samples_per_step": n_track,
                        "segment_seconds_per_s": round(seg_s / elapsed, 2),
-                       "track_4min_xRT": track_4min, "track_strong_xRT": track_strong,
+                       # scalars (nested objects are dropped by the driver's parser)
+                       "track_4min_host_xRT": None if track_4min is None else track_4min["xRT"],
+                       "track_4min_host_wall_s": None if track_4min is None else min(track_4min["wall_s"]),
+                       "track_4min_host_MB_in_out": None if track_4min is None else track_4min["host_MB_in_out"],
+                       "track_strong_xRT": None if track_strong is None else track_strong["xRT"],
+                       "track_strong_wall_s": None if track_strong is None else min(track_strong["wall_s"]),
+                       "track_strong_ranks": None if track_strong is None else track_strong["ranks"],
                        "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        # the latency point against the same roofline: 340.2 GFLOP in one call vs the fp32 MFMA peak
-                       "single_segment_tflops": None if single_ms is None else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12, 2),
-                       "single_segment_roofline_frac": None if single_ms is None else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12 / PEAK_TFLOPS_FP32_MFMA, 4),
+                       "single_segment_tflops": None if single_ms is None or v3 else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12, 2),
+                       "single_segment_roofline_frac": None if single_ms is None or v3 else round(MODEL_FLOPS_4S / (single_ms * 1e-3) / 1e12 / PEAK_TFLOPS_FP32_MFMA, 4),
                        "parallelism": f"segment-sharded x{world}"},
         }
         if roofline:

@@ -94,7 +94,7 @@ extern "C" int dmx_model_clone(const dmx_model *src, int device, dmx_model **out
     if (device < 0 || device >= ndev)
         return fail(DMX_ERR_ARG, "dmx_model_clone: device %d out of range (have %d)", device, ndev);
     auto m = std::make_unique<dmx_model>();
-    m->pm.n_sources = src->pm.n_sources, m->pm.dim = src->pm.dim, m->pm.n_tensors = src->pm.n_tensors;
+    m->pm.arch = src->pm.arch, m->pm.n_sources = src->pm.n_sources, m->pm.dim = src->pm.dim, m->pm.n_tensors = src->pm.n_tensors;
     m->pm.index = src->pm.index; // offsets only: the plan never reads the host blob
     m->blobFloats = src->blobFloats;
     m->device = device;

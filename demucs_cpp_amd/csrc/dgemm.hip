@@ -486,6 +486,10 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
         DMX_D(6, 1, 8, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0)
         DMX_D(12, 1, 12, PRO_GN_GELU, EPI_STATS_ONLY, 0)
         DMX_D(12, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1)
+        // Demucs v3 DConv (hidden C/4): k3 for hidden 12 (C=48) / 24 (C=96), factorised statistics for hidden 24
+        DMX_D(6, 1, 12, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0)
+        DMX_D(12, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1)
+        DMX_D(2, 1, 24, PRO_GN_GELU, EPI_STATS_FACT, 0)
         // first encoder convs (z-norm prologue) k8 s4: Cin = 4 (freq), 2 (time)
         DMX_D(3, 1, 32, PRO_AFFINE, EPI_LINEAR, 0)
         DMX_D(3, 1, 16, PRO_AFFINE, EPI_LINEAR, 0)

@@ -132,6 +132,9 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi)
         6 * 1000000 + 1 * 100000 + 8 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
         12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_STATS_ONLY,
         12 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
+        6 * 1000000 + 1 * 100000 + 12 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,  // Demucs v3: hidden C/4
+        12 * 1000000 + 1 * 100000 + 24 * 100 + PRO_GN_GELU * 10 + EPI_GN_GLU_SCALE_RES,
+        2 * 1000000 + 1 * 100000 + 24 * 100 + PRO_GN_GELU * 10 + EPI_STATS_FACT,
         3 * 1000000 + 1 * 100000 + 32 * 100 + PRO_AFFINE * 10 + EPI_LINEAR,
         3 * 1000000 + 1 * 100000 + 16 * 100 + PRO_AFFINE * 10 + EPI_LINEAR,
         6 * 1000000 + 1 * 100000 + 48 * 100 + PRO_NONE * 10 + EPI_GLU,

@@ -45,6 +45,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <memory>
 #include <string>
@@ -228,10 +229,26 @@ static Model *load_model(const char *path)
 // src/conv.hpp:110,181,366,437 and src/layers.cpp:426-431,467-468,479,488,501,507.
 // fp32 accumulate in k order per output (blocked over k for cache only).
 // ---------------------------------------------------------------------------------
+// Optional BLAS back end for the cpu_baseline leg of bench.py (BASELINE.json configs[0] names "Eigen/OpenBLAS"):
+// cblas_sgemm of the OpenBLAS that NumPy bundles (ILP64 symbol scipy_cblas_sgemm64_), bound at run time by
+// orc_use_blas(). Off by default: parity tests use the oracle's own k-ordered SGEMM.
+typedef void (*cblas_sgemm64_fn)(int, int, int, int64_t, int64_t, int64_t, float, const float *, int64_t, const float *, int64_t,
+                                 float, float *, int64_t);
+static cblas_sgemm64_fn g_cblas_sgemm = nullptr;
+
 static void sgemm_nt(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
                      const float *B, int64_t ldb, float *C, int64_t ldc,
                      const float *bias)
 {
+    if (g_cblas_sgemm)
+    {
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; ++m)
+            for (int64_t n = 0; n < N; ++n)
+                C[m * ldc + n] = bias ? bias[n] : 0.0f;
+        g_cblas_sgemm(101 /*RowMajor*/, 111 /*NoTrans*/, 112 /*Trans*/, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc);
+        return;
+    }
     // transpose B to [K][N] so the inner loop vectorises over n
     std::vector<float> Bt((size_t)(K * N));
     for (int64_t n = 0; n < N; ++n)
@@ -1831,6 +1848,29 @@ extern "C"
         orc::segment_inference_any(*(orc::Model *)m, mix, seg, out);
     }
     int orc_model_arch(void *m) { return ((orc::Model *)m)->arch; }
+    // binds (path != null) or unbinds (null) an ILP64 cblas_sgemm for the oracle's GEMMs; returns 0 on success
+    int orc_use_blas(const char *lib_path, const char *symbol)
+    {
+        if (!lib_path)
+        {
+            orc::g_cblas_sgemm = nullptr;
+            return 0;
+        }
+        void *h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+        {
+            orc::g_last_error = std::string("dlopen failed: ") + dlerror();
+            return -1;
+        }
+        void *f = dlsym(h, symbol);
+        if (!f)
+        {
+            orc::g_last_error = std::string("symbol not found: ") + symbol;
+            return -1;
+        }
+        orc::g_cblas_sgemm = (orc::cblas_sgemm64_fn)f;
+        return 0;
+    }
     // audio (2, N) planar -> out (S, 2, N) planar
     void orc_track_infer(void *m, const float *audio, int64_t N, int shift_offset, int64_t seg,
                          float *out)

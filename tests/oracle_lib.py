@@ -50,11 +50,27 @@ def lib():
         L.orc_sin_embedding_1d.argtypes = [i64, i64, f32p]
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
         L.orc_model_arch.argtypes = [vp]
+        L.orc_use_blas.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.orc_group_norm_g.argtypes = [f32p, i64, i64, i64, f32p, f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int]
         L.orc_lstm.argtypes = [vp, ctypes.c_char_p, f32p, i64, i64, f32p]
         L.orc_local_attention.argtypes = [vp, ctypes.c_char_p, f32p, i64, i64]
         _lib = L
     return _lib
+
+
+def use_openblas(on=True):
+    """cpu_baseline leg only: route the oracle's GEMMs through the OpenBLAS bundled with NumPy (ILP64 cblas_sgemm).
+    Returns the library path, or None when it cannot be found / bound (the own SGEMM stays in place)."""
+    import glob
+    if not on:
+        lib().orc_use_blas(None, None)
+        return None
+    base = os.path.dirname(os.path.dirname(np.__file__))
+    cands = glob.glob(os.path.join(base, "numpy.libs", "libscipy_openblas64_*.so"))
+    for c in cands:
+        if lib().orc_use_blas(c.encode(), b"scipy_cblas_sgemm64_") == 0:
+            return c
+    return None
 
 
 def _f32(a):

@@ -14,6 +14,52 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
+def sdr_db(ref, est):
+    num = float((np.asarray(ref, np.float64) ** 2).sum())
+    den = float(((np.asarray(ref, np.float64) - np.asarray(est, np.float64)) ** 2).sum())
+    return 10 * np.log10(max(num, 1e-300) / max(den, 1e-300))
+
+
+# LOCAL parity metrics: the global max-abs / max-abs figure lets a stem, a channel or a quiet
+# passage 40 dB below the loudest one be entirely wrong. These look at every stem and every block on its own scale.
+LOCAL_TOL = 1e-3       # error of a block / channel relative to ITS OWN max-abs ...
+LOCAL_FLOOR = 1e-2     # ... floored at 1 % (-40 dB) of the containing stem's / tensor's max-abs
+MIN_STEM_SDR_DB = 60.0
+
+
+def local_errors(got, ref, block=4096):
+    """got, ref: (S, 2, n) stems. Returns (worst blockwise relative error, worst per-stem SDR in dB)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    worst, worst_sdr = 0.0, np.inf
+    for s in range(ref.shape[0]):
+        smax = max(np.abs(ref[s]).max(), 1e-30)
+        worst_sdr = min(worst_sdr, sdr_db(ref[s], got[s]))
+        n = ref.shape[-1]
+        nb = (n + block - 1) // block
+        pad = nb * block - n
+        r = np.pad(ref[s], ((0, 0), (0, pad))).reshape(ref.shape[1], nb, block)
+        d = np.pad(got[s] - ref[s], ((0, 0), (0, pad))).reshape(ref.shape[1], nb, block)
+        scale = np.maximum(np.abs(r).max(axis=-1), LOCAL_FLOOR * smax)
+        worst = max(worst, float((np.abs(d).max(axis=-1) / scale).max()))
+    return worst, float(worst_sdr)
+
+
+def assert_local_parity(got, ref, block=4096, tol=LOCAL_TOL, what="output"):
+    worst, wsdr = local_errors(got, ref, block)
+    assert worst < tol, f"{what}: blockwise relative error {worst:.3e} >= {tol:g} (block {block}, floor -40 dB per stem)"
+    assert wsdr > MIN_STEM_SDR_DB, f"{what}: worst per-stem SDR {wsdr:.1f} dB <= {MIN_STEM_SDR_DB} dB"
+
+
+def channel_relerr(g, r):
+    """Tap tensors in the oracle's layout (channel first): worst per-channel error relative to that channel's own
+    max-abs, floored at -40 dB of the tensor's max-abs."""
+    g = np.asarray(g, np.float64).reshape(g.shape[0], -1)
+    r = np.asarray(r, np.float64).reshape(r.shape[0], -1)
+    scale = np.maximum(np.abs(r).max(axis=1), LOCAL_FLOOR * max(np.abs(r).max(), 1e-30))
+    return float((np.abs(g - r).max(axis=1) / scale).max())
+
+
 def gpu_tap_as_oracle(ctx, name, b=0):
     """Returns the GPU tap `name` of batch element b re-laid-out like the oracle's tap."""
     a = ctx.tap(name)
@@ -64,11 +110,17 @@ def oracle_tap_v3(name):
     return np.squeeze(orc.tap(name))
 
 
-def compare_segment(ctx, omodel, mix, b=0, taps=True):
-    """mix (2, seg). Runs oracle + GPU; returns (errors dict, gpu_out, oracle_out)."""
+LAST_LOCAL = {}  # name -> local (per-channel / blockwise) error of the last compare_segment call
+
+
+def compare_segment(ctx, omodel, mix, b=0, taps=True, local=True):
+    """mix (2, seg). Runs oracle + GPU; returns (errors dict, gpu_out, oracle_out). errs holds the global
+    max-abs / max-abs figures; with local=True the per-channel (taps) and blockwise + per-stem-SDR (output) metrics
+    are ASSERTED here as well (LOCAL_TOL, MIN_STEM_SDR_DB) and kept in LAST_LOCAL."""
     ref = omodel.segment(mix, taps=taps)
     out = ctx.segment(mix)
     errs = {}
+    LAST_LOCAL.clear()
     if taps and getattr(omodel, "arch", 4) == 3:
         for name in V3_TAPS:
             g = gpu_tap_as_oracle_v3(ctx, name, b)
@@ -78,6 +130,8 @@ def compare_segment(ctx, omodel, mix, b=0, taps=True):
             r = oracle_tap_v3(name)
             g = np.squeeze(g)
             errs[name] = relerr(g, r) if g.shape == r.shape else float("nan")
+            if g.shape == r.shape:
+                LAST_LOCAL[name] = channel_relerr(g, r)
     elif taps:
         for name in TAPS:
             g = gpu_tap_as_oracle(ctx, name, b)
@@ -85,5 +139,12 @@ def compare_segment(ctx, omodel, mix, b=0, taps=True):
                 continue
             r = oracle_tap(name)
             errs[name] = relerr(g, r) if g.shape == r.shape else float("nan")
+            if g.shape == r.shape and name != "x_cac":  # (x_cac: 4 CaC planes, channel axis = re/im of one spectrum)
+                LAST_LOCAL[name] = channel_relerr(np.squeeze(g), np.squeeze(r))
     errs["out"] = relerr(out, ref)
+    if local:
+        bad = {k: v for k, v in LAST_LOCAL.items() if not (v < LOCAL_TOL)}
+        assert not bad, f"per-channel relative error of taps above {LOCAL_TOL:g}: {bad}"
+        assert_local_parity(out, ref, what="segment output")
+        LAST_LOCAL["out_block"], LAST_LOCAL["out_min_stem_sdr_db"] = local_errors(out, ref)
     return errs, out, ref

@@ -52,6 +52,45 @@ def test_cli_reads_driver_stems(tmp_path):
 
 
 @pytest.mark.gpu
+def test_checkpoint_to_sdr_pipeline_on_a_random_init_hub_checkpoint(tmp_path):
+    """The whole real-weights procedure with everything but the weights being real: a random-init
+    HTDemucs state dict in the torch-hub layout ({"state": ...}, fp16, PyTorch's un-squeezed conv shapes) ->
+    tools/convert_pth_to_dmc.py -> cli/demucs.cpp.main on the reference's benchmark file (shift offset 1337, the one of
+    .github/SDR_scores.md:21) -> tools/eval_sdr.py with the ORACLE's stems standing in for the ground truth: every target's
+    median windowed SDR of GPU vs oracle > 60 dB. What is left for the reference's SDR table is the checkpoint itself
+    (test_real_weights_sdr_matches_reference_scores)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from wavio import read_wav, write_wav_f32
+    from test_convert_tool import unsqueezed_state
+    _, state = unsqueezed_state(4, 21)
+    ck = str(tmp_path / "955717e8-random.th")
+    torch.save({"state": {k: v.half() for k, v in state.items()}, "klass": "HTDemucs", "args": (), "kwargs": {}}, ck)
+    model = str(tmp_path / "ggml-model-htdemucs-4s-f16.bin")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convert_pth_to_dmc.py"), ck, model])
+    wav = os.path.join(ROOT, "tests", "golden", "gspi_stereo.wav")
+    exe = os.path.join(ROOT, "cli", "demucs.cpp.main")
+    out_dir, ref_dir = tmp_path / "stems", tmp_path / "oracle"
+    ref_dir.mkdir()
+    subprocess.check_call([exe, model, wav, str(out_dir)], env=dict(os.environ, DMX_SHIFT_OFFSET="1337", DMX_BATCH="2"))
+    _, audio = read_wav(wav)
+    orc.lib().orc_set_num_threads(min(32, os.cpu_count() or 1))
+    om = orc.OracleModel(model)
+    ref = om.track(audio, 1337)
+    om.close()
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        write_wav_f32(str(ref_dir / f"{name}.wav"), ref[i])
+    refs, ests = eval_sdr.load_dirs(str(ref_dir), str(out_dir))
+    got = eval_sdr.track_sdr(refs, ests)
+    assert sorted(got) == ["bass", "drums", "other", "vocals"]
+    for name, v in got.items():
+        assert v > 60.0, (name, v)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_sdr.py"), str(ref_dir), str(out_dir)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.count("SDR") == 4
+
+
+@pytest.mark.gpu
 def test_real_weights_sdr_matches_reference_scores(tmp_path):
     """Opt-in: DMX_REAL_WEIGHTS = a htdemucs PyTorch checkpoint (.th) or a converted ggml-model-htdemucs-4s-f16.bin,
     DMX_MUSDB_TRACK = directory with mixture.wav + {drums,bass,other,vocals}.wav of 'Zeno - Signs' (MUSDB18-HQ test).

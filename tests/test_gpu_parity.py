@@ -152,6 +152,7 @@ def test_track_vs_oracle_reduced(n_mult, shift, dmx, tmp_models, oracle_threads)
     msgs = []
     got = ctx.track(audio, shift, progress=lambda p, s: msgs.append((p, s)))
     assert pu.relerr(got, ref) < TOL
+    pu.assert_local_parity(got, ref, what="track")  # per stem, per 4096-sample block
     assert msgs and abs(msgs[-1][0] - 1.0) < 1e-6
     ctx.close(); m.close(); om.close()
 
@@ -634,6 +635,7 @@ def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
             assert not mix_g[:, :left].any() and not mix_g[:, left + last_chunk:].any() and mix_g[:, left:left + last_chunk].any()
         o_ref = om.segment(mix_g)
         assert np.abs(seg_out[g] - o_ref).max() <= TOL * np.abs(o_ref).max()
+        pu.assert_local_parity(seg_out[g], o_ref, what=f"segment {g} of the 4-minute track")
     om.close(); ctx.close(); m.close()
 
 
@@ -649,10 +651,61 @@ def test_stress_models_full_size_vs_oracle(variant, dmx, tmp_path, oracle_thread
     write_synthetic_model(path, 4, 7, variant)
     mix = (0.1 * np.random.default_rng(8).standard_normal((2, SEG_FULL)) + 0.3).astype(np.float32)
     m = dmx.Model(path); ctx = dmx.Context(m, 0, 1); om = orc.OracleModel(path)
-    errs, out, ref = pu.compare_segment(ctx, om, mix)
+    errs, out, ref = pu.compare_segment(ctx, om, mix)  # also asserts the per-channel / blockwise / per-stem-SDR metrics
     bad = {k: v for k, v in errs.items() if not (v < TOL)}
     assert not bad, bad
     assert np.isfinite(out).all()
+    ctx.close(); m.close(); om.close()
+
+
+def test_reference_benchmark_file_through_track_and_cli_vs_oracle(dmx, tmp_models, golden_dir, tmp_path, oracle_threads):
+    """test/data/gspi_stereo.wav - real music, the file behind every number of the reference's
+    .github/benchmark_output.txt:7 (two segments at any shift) - through dmx_track_infer AND cli/demucs.cpp.main, against the
+    ORACLE's demucs_inference (not against the library itself): global, per-stem SDR and blockwise metrics."""
+    import subprocess
+    from wavio import read_wav
+    wav = os.path.join(golden_dir, "gspi_stereo.wav")
+    rate, audio = read_wav(wav)
+    assert rate == 44100 and audio.shape == (2, 262144)
+    shift = 4033  # the first unseeded glibc rand() % 22050: what the reference's benchmark runs used
+    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 2); om = orc.OracleModel(tmp_models[4])
+    assert ctx.track_geometry(audio.shape[1], shift)[1] == 2
+    ref = om.track(audio, shift)
+    got = ctx.track(audio, shift)
+    assert pu.relerr(got, ref) < TOL
+    pu.assert_local_parity(got, ref, what="gspi_stereo track")
+    exe = os.path.join(ROOT, "cli", "demucs.cpp.main")
+    assert os.path.exists(exe), "CLI not built"
+    out_dir = tmp_path / "stems"
+    r = subprocess.run([exe, tmp_models[4], wav, str(out_dir)], env=dict(os.environ, DMX_SHIFT_OFFSET=str(shift), DMX_BATCH="2"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    stems = np.stack([read_wav(str(out_dir / f"target_{i}_{nm}.wav"))[1] for i, nm in enumerate(["drums", "bass", "other", "vocals"])])
+    assert np.array_equal(stems, got)
+    pu.assert_local_parity(stems, ref, what="gspi_stereo CLI stems")
+    ctx.close(); m.close(); om.close()
+
+
+@pytest.mark.parametrize("gain", [0.25, 4.0])
+def test_weight_scale_sweep_vs_oracle(gain, dmx, tmp_path, oracle_threads):
+    """Where in DESIGN.md section 3's error envelope does a checkpoint with larger / smaller weights sit? Every conv / linear
+    / attention weight of the default synthetic model scaled by `gain` (norm affines, biases and LayerScale untouched):
+    activations between norms change by up to gain^depth while every norm brings them back - the regime trained
+    checkpoints live in. Full-size segment, all taps, global + local metrics."""
+    from demucs_cpp_amd.weights import synth_weights, write_model, tensor_catalogue
+    w = synth_weights(4, 0)
+    for name, _ in tensor_catalogue(4):
+        is_norm = ".norm" in name or name.endswith(".1.weight") or name.endswith(".4.weight")
+        if (name.endswith("weight") or name.endswith("in_proj_weight")) and not is_norm and "freq_emb" not in name:
+            w[name] = (w[name].astype(np.float32) * gain).astype(np.float16)
+    path = str(tmp_path / f"gain{gain}-4s.bin")
+    write_model(path, w, 4)
+    mix = (0.1 * np.random.default_rng(18).standard_normal((2, SEG_FULL))).astype(np.float32)
+    m = dmx.Model(path); ctx = dmx.Context(m, 0, 1); om = orc.OracleModel(path)
+    errs, out, ref = pu.compare_segment(ctx, om, mix)
+    bad = {k: v for k, v in errs.items() if not (v < TOL)}
+    assert not bad, bad
+    print(f"gain {gain}: worst global tap error {max(errs.values()):.2e}, local {pu.LAST_LOCAL}")
     ctx.close(); m.close(); om.close()
 
 

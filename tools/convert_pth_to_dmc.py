@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""PyTorch HTDemucs checkpoint -> dmc4 / dmc6 weight file (the counterpart of
+"""PyTorch HTDemucs / HDemucs checkpoint -> dmc4 / dmc6 / dmc3 weight file (the counterpart of
 /root/reference/scripts/convert-pth-to-ggml.py:111-140, without its dependency on the `demucs`
 package and the torch-hub download):
 
     python tools/convert_pth_to_dmc.py  955717e8-8726e21a.th  out/ggml-model-htdemucs-4s-f16.bin
     python tools/convert_pth_to_dmc.py  5c90dfd2-34c22ccb.th  out/ggml-model-htdemucs-6s-f16.bin
+    python tools/convert_pth_to_dmc.py  75fc33f5-1941ce65.th  out/ggml-model-hdemucs_mmi-v3-f16.bin   (Demucs v3, magic dmc3)
 
 Input: a file `torch.load` can read that holds either the state dict itself or the hub checkpoint
 `{"state": state_dict, ...}` (what facebookresearch/demucs publishes). Every tensor is written in
@@ -20,23 +21,27 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from demucs_cpp_amd.weights import tensor_catalogue, write_model  # noqa: E402
+from demucs_cpp_amd.weights import tensor_catalogue, tensor_catalogue_v3, write_model  # noqa: E402
 
 
 def convert(state, strict=True):
-    """state: name -> array-like (torch tensors or numpy). Returns (n_sources, ordered dict of fp16 arrays)."""
+    """state: name -> array-like (torch tensors or numpy). Returns (n_sources, ordered dict of fp16 arrays, problems);
+    n_sources == 3 tags the Demucs v3 (hdemucs_mmi) architecture, which has 4 stems (weights.read_model convention)."""
     tensors = {}
     for name, t in state.items():
         a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
         tensors[name] = np.ascontiguousarray(np.squeeze(a).astype(np.float16))
-    key = "decoder.3.conv_tr.bias"
-    if key not in tensors:
-        raise ValueError(f"not an HTDemucs state dict: '{key}' missing")
-    n_out = int(tensors[key].shape[0])  # 4 * S (complex-as-channels x stereo x sources)
-    if n_out not in (16, 24):
-        raise ValueError(f"unsupported number of sources: decoder.3.conv_tr.bias has {n_out} channels")
-    ns = n_out // 4
-    cat = dict(tensor_catalogue(ns))
+    if "encoder.4.dconv.layers.0.3.lstm.weight_ih_l0" in tensors:  # the BiLSTM of levels 4 / 5 exists in v3 only
+        ns, cat = 3, dict(tensor_catalogue_v3())
+    else:
+        key = "decoder.3.conv_tr.bias"
+        if key not in tensors:
+            raise ValueError(f"not an HTDemucs / HDemucs state dict: '{key}' missing")
+        n_out = int(tensors[key].shape[0])  # 4 * S (complex-as-channels x stereo x sources)
+        if n_out not in (16, 24):
+            raise ValueError(f"unsupported number of sources: decoder.3.conv_tr.bias has {n_out} channels")
+        ns = n_out // 4
+        cat = dict(tensor_catalogue(ns))
     problems = []
     for name, shape in cat.items():
         if name not in tensors:
@@ -65,7 +70,7 @@ def main():
     for pmsg in problems:
         print("warning:", pmsg, file=sys.stderr)
     os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
-    write_model(args.output, tensors, ns)
+    write_model(args.output, tensors, 4 if ns == 3 else ns, "v3" if ns == 3 else "v4")
     print(f"wrote {args.output}: dmc{ns}, {len(tensors)} tensors, {os.path.getsize(args.output) / 1e6:.1f} MB")
 
 
