@@ -13,6 +13,10 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 __device__ __forceinline__ float v3_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+// the LSTM's gates sit on the critical path of 2016 sequential steps: v_exp_f32 / v_rcp_f32 forms (1 ulp each; the
+// absolute error of the tanh form is < 2e-7, the parity tolerance 1e-4)
+__device__ __forceinline__ float lstm_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float lstm_tanh(float v) { return 2.0f * lstm_sigmoid(2.0f * v) - 1.0f; }
 
 // --------------------------------------------------------------------------- GroupNorm statistics
 // One workgroup per (group, batch element): two passes over the group's rows x C/G elements (the second one hits
@@ -155,7 +159,7 @@ void launch_gn_act(const GnActArgs &a, hipStream_t s)
 // --------------------------------------------------------------------------- bidirectional LSTM layer (recurrent part)
 // The recurrence h_t = f(W_hh h_{t-1} + xproj_t) is sequential in t (336 / 168 steps) and W_hh of one direction
 // (590 KB at H = 192, 2.36 MB at H = 384, fp32) fits neither one CU's registers nor its LDS, so one recurrence =
-// one (direction, group of 16 batch columns) is run by P cooperating workgroups of 8 waves:
+// one (direction, group of 16 batch columns) is run by P cooperating workgroups of NW = 4 (or 8) waves:
 //   * a wave owns FR fragments of 16 gate rows = 4 hidden units x (i, f, g, o); its slice of W_hh stays in registers
 //     for all steps as MFMA A operands (v_mfma_f32_16x16x4_f32: gate rows x batch columns, k = hidden units);
 //     the accumulator starts from the input projection, so a lane ends a step holding the four gates of ONE
@@ -169,15 +173,15 @@ void launch_gn_act(const GnActArgs &a, hipStream_t s)
 //   * the workgroups of one recurrence are placed on one XCD (block b runs on XCD b % 8: speed only).
 // The granule area is zeroed by the launcher before every launch (tags of an earlier launch must never match).
 // Spins are bounded: on a time-out the kernel raises `status` and carries on with whatever it read.
-template <int H, int FR>
-__global__ __launch_bounds__(512) void lstm_kernel(const LstmArgs p)
+template <int H, int FR, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_kernel(const LstmArgs p)
 {
     constexpr int UW = 4 * FR;   // hidden units per wave
-    constexpr int UWG = 8 * UW;  // per workgroup
+    constexpr int UWG = NW * UW; // per workgroup
     constexpr int P = H / UWG;   // workgroups per recurrence
     constexpr int HP = H + 4;    // LDS row pitch (floats): 16 columns x ds_read_b128 hit 64 distinct banks
     constexpr int NJ = H / 16;   // float4 k-steps per fragment
-    constexpr int NPOLL = H / 32; // granule loads per lane and step (a wave sweeps H/8 units x 16 columns)
+    constexpr int NPOLL = H / (4 * NW); // granule loads per lane and step (a wave sweeps H/NW units x 16 columns)
     static_assert(H % UWG == 0, "units split evenly");
     __shared__ float hs[2][16][HP];
 
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(512) void lstm_kernel(const LstmArgs p)
         }
         if (step > 0)
         {
-            // ---- poll h_{step-1}: this wave sweeps units [wave H/8, +H/8) of all 16 columns until every tag == step
-            const gu64 *src = gran + (i64)((step - 1) & 1) * H * 16 + (i64)(wave * (H / 8)) * 16 + lane;
+            // ---- poll h_{step-1}: this wave sweeps units [wave H/NW, +H/NW) of all 16 columns until every tag == step
+            const gu64 *src = gran + (i64)((step - 1) & 1) * H * 16 + (i64)(wave * (H / NW)) * 16 + lane;
             float hv[NPOLL];
             unsigned spins = 0;
             for (;;)
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(const LstmArgs p)
             float(*hb)[HP] = hs[step & 1];
 #pragma unroll
             for (int n = 0; n < NPOLL; ++n)
-                hb[l15][wave * (H / 8) + 4 * n + kq] = hv[n]; // granule (unit, column) -> hs[column][unit]
+                hb[l15][wave * (H / NW) + 4 * n + kq] = hv[n]; // granule (unit, column) -> hs[column][unit]
             __syncthreads();
             // ---- gates += W_hh h: B operand lane (column l15, k-slot kq) holds h[16 jj + 4 kq + c]. Two accumulator
             // chains per fragment (even / odd k sub-step): the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one
@@ -282,10 +286,10 @@ __global__ __launch_bounds__(512) void lstm_kernel(const LstmArgs p)
 #pragma unroll
         for (int f = 0; f < FR; ++f)
         {
-            const float ig = v3_sigmoid(acc[f][0]), fg = v3_sigmoid(acc[f][1]), gg = tanhf(acc[f][2]), og = v3_sigmoid(acc[f][3]);
+            const float ig = lstm_sigmoid(acc[f][0]), fg = lstm_sigmoid(acc[f][1]), gg = lstm_tanh(acc[f][2]), og = lstm_sigmoid(acc[f][3]);
             const float cn = fg * cst[f] + ig * gg;
             cst[f] = cn;
-            const float h = og * tanhf(cn);
+            const float h = og * lstm_tanh(cn);
             const int unit = ub + 4 * f + kq;
             if (step + 1 < p.T)
                 __hip_atomic_store(dst + (i64)unit * 16 + l15, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(h),
@@ -296,13 +300,13 @@ __global__ __launch_bounds__(512) void lstm_kernel(const LstmArgs p)
     }
 }
 
-template <int H, int FR>
+template <int H, int FR, int NW>
 static void launch_lstm_t(const LstmArgs &a, hipStream_t s)
 {
-    constexpr int P = H / (32 * FR);
+    constexpr int P = H / (4 * FR * NW);
     const int nGroups = 2 * ((a.B + 15) / 16);
     const unsigned blocks = 8u * P * (unsigned)((nGroups + 7) / 8);
-    hipLaunchKernelGGL((lstm_kernel<H, FR>), dim3(blocks), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((lstm_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
 }
 
 int launch_lstm(const LstmArgs &a, hipStream_t s)
@@ -310,10 +314,14 @@ int launch_lstm(const LstmArgs &a, hipStream_t s)
     // tags of an earlier launch must never satisfy a poll of this one
     if (hipMemsetAsync(a.gran, 0, (size_t)lstm_sync_floats(a.B, a.H) * sizeof(float), s) != hipSuccess)
         return -1;
+    // workgroup shape (env DMX_LSTM_WAVES = 4 | 8, default 4): 4 waves = ONE wave per SIMD, i.e. the 32-cycle fp32 MFMAs of
+    // a step are not shared with a second wave (the recurrence is latency-bound: a step cannot start before the
+    // previous one's h has crossed the chip); the price is twice the workgroups polling the same granules
+    static const int nw = getenv("DMX_LSTM_WAVES") ? atoi(getenv("DMX_LSTM_WAVES")) : 4;
     if (a.H == 192)
-        launch_lstm_t<192, 1>(a, s);
+        nw == 8 ? launch_lstm_t<192, 1, 8>(a, s) : launch_lstm_t<192, 1, 4>(a, s);
     else if (a.H == 384)
-        launch_lstm_t<384, 1>(a, s);
+        nw == 8 ? launch_lstm_t<384, 1, 8>(a, s) : launch_lstm_t<384, 1, 4>(a, s);
     else
         return -1;
     return 0;
