@@ -412,7 +412,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_GROUP_STATS:
     {
         const GroupStats &g = op.gs;
-        launch_group_stats(GroupStatsArgs{a(g.x), a(g.out), g.B, g.rows, g.C, g.G, g.eps}, s);
+        launch_group_stats(GroupStatsArgs{a(g.x), a(g.out), reinterpret_cast<double *>(a(g.scratch)), g.B, g.rows, g.C, g.G, g.eps}, s);
         break;
     }
     case OP_GN_ACT:

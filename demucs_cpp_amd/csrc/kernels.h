@@ -159,6 +159,7 @@ struct GroupStatsArgs
 {
     const float *x;
     float *out;
+    double *partials; // [B][G][32 chunks][2]
     int B, rows, C, G;
     float eps;
 };

@@ -863,6 +863,7 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
     case OP_GROUP_STATS:
         R(op.gs.x, (i64)op.gs.B * op.gs.rows * op.gs.C);
         Wr(op.gs.out, (i64)op.gs.B * op.gs.G * 4);
+        Wr(op.gs.scratch, (i64)op.gs.B * op.gs.G * 32 * 4);
         break;
     case OP_GN_ACT:
     {
@@ -1024,6 +1025,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
     const i64 aLu = b.alloc((i64)B * std::max((i64)T * 1536, (i64)T5 * 3072));
     const i64 aLsync = b.alloc(lstm_sync_floats(B, 384));
     const i64 aStG = b.alloc((i64)B * 4 * 4), aStGt = b.alloc((i64)B * 4 * 4);
+    const i64 aGsScr = b.alloc((i64)B * 4 * 32 * 4), aGsScrT = b.alloc((i64)B * 4 * 32 * 4); // chunk partials (doubles), per stream
     // decoders 0 / 1, tdecoder 0
     const int Lz0 = 2 * T5 + 2, Lzt = 4 * T + 4;
     const i64 aD0r = b.alloc((i64)B * T5 * 3072), aD0g = b.alloc((i64)B * T5 * 1536), aD0t = b.alloc((i64)B * Lz0 * 768);
@@ -1049,7 +1051,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
         op.kind = OP_GROUP_STATS;
         op.stream = stream;
         op.name = name;
-        op.gs = GroupStats{x, aStG, B, rows, C, Gn, 1e-5f};
+        op.gs = GroupStats{x, aStG, B, rows, C, Gn, 1e-5f, aGsScr};
         pl.ops.push_back(op);
     };
     auto gnact = [&](const std::string &name, int stream, i64 x, i64 y, int rowsIn, int C, int Gn, int mode, i64 w, i64 bs,
@@ -1319,7 +1321,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
         op.kind = OP_GROUP_STATS;
         op.stream = 1;
         op.name = "tdecoder.0.norm2.stats";
-        op.gs = GroupStats{aTD0t, aStGt, B, Lzt, 384, 4, 1e-5f};
+        op.gs = GroupStats{aTD0t, aStGt, B, Lzt, 384, 4, 1e-5f, aGsScrT};
         pl.ops.push_back(op);
         // GELU, crop [2, 2 + L3), and the skip add of tdecoder 1
         Op o2;

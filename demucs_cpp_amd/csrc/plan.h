@@ -195,6 +195,7 @@ struct GroupStats
     i64 out; // A: [B][G][4] {mean, rstd, std, 0}
     int B, rows, C, G;
     float eps;
+    i64 scratch; // A: [B][G][32][2] doubles (chunk partials of the two-launch reduction; 8-byte aligned)
 };
 // y[b][r][c'] = f(x[b][r + rowOff][.]) for r < rowsOut:
 //   mode 0: v = gn(x[c]);  mode 1: v = gelu(gn(x[c]));  mode 2 (GLU): v = gn(x[c]) * sigmoid(gn(x[c + C/2])), C' = C/2;

@@ -19,72 +19,74 @@ __device__ __forceinline__ float lstm_sigmoid(float v) { return __builtin_amdgcn
 __device__ __forceinline__ float lstm_tanh(float v) { return 2.0f * lstm_sigmoid(2.0f * v) - 1.0f; }
 
 // --------------------------------------------------------------------------- GroupNorm statistics
-// One workgroup per (group, batch element): two passes over the group's rows x C/G elements (the second one hits
-// L2), double accumulators, fixed reduction tree: the record depends on nothing but the group's data.
-__global__ __launch_bounds__(1024) void group_stats_kernel(const GroupStatsArgs p)
+// Two launches: kStatChunks workgroups per (group, batch element) each reduce a fixed row range to (sum, sum of
+// squares) in DOUBLE (one pass: with fp64 accumulators the subtraction n*mean^2 costs nothing for |mean| / sigma
+// up to 1e6), then one wave per (group, batch element) adds the chunk partials in index order. The record depends
+// on nothing but the group's data and the fixed chunking (rows per chunk = ceil(rows / kStatChunks)).
+static const int kStatChunks = 32;
+__global__ __launch_bounds__(256) void group_stats_partial_kernel(const GroupStatsArgs p)
 {
-    const int g = blockIdx.x, b = blockIdx.y;
+    const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int gs = p.C / p.G, gs4 = gs >> 2;
+    const int rpc = (p.rows + kStatChunks - 1) / kStatChunks;
+    const int r0 = ch * rpc, r1 = min(p.rows, r0 + rpc);
     const float *x = p.x + (i64)b * p.rows * p.C + (i64)g * gs;
-    const i64 n4 = (i64)p.rows * gs4;
-    __shared__ double red[16];
-    __shared__ float meanS;
-    auto block_sum = [&](double v) -> double {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            v += __shfl_xor(v, off);
-        __syncthreads(); // red[] of the previous reduction has been consumed
-        if ((threadIdx.x & 63) == 0)
-            red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        double t = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w)
-            t += red[w];
-        return t;
-    };
-    double s = 0;
-    for (i64 i = threadIdx.x; i < n4; i += 1024)
+    double s = 0, q = 0;
+    const i64 n4 = (i64)max(r1 - r0, 0) * gs4;
+    for (i64 i = threadIdx.x; i < n4; i += 256)
     {
-        const i64 r = i / gs4;
-        const int c4 = (int)(i - r * gs4);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * p.C + 4 * c4);
-        s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
-    }
-    const double cnt = (double)p.rows * gs;
-    const double tot = block_sum(s);
-    if (threadIdx.x == 0)
-        meanS = (float)(tot / cnt);
-    __syncthreads();
-    const float mean = meanS;
-    double q = 0;
-    for (i64 i = threadIdx.x; i < n4; i += 1024)
-    {
-        const i64 r = i / gs4;
-        const int c4 = (int)(i - r * gs4);
+        const i64 r = r0 + i / gs4;
+        const int c4 = (int)(i % gs4);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * p.C + 4 * c4);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-            const double d = (double)v[k] - (double)mean;
-            q += d * d;
+            s += (double)v[k];
+            q += (double)v[k] * (double)v[k];
         }
     }
-    const double ss = block_sum(q);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    __shared__ double red[4][2];
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6][0] = s, red[threadIdx.x >> 6][1] = q;
+    __syncthreads();
     if (threadIdx.x == 0)
     {
-        const double var = ss / (cnt - 1.0); // unbiased (Q3)
-        float *o = p.out + ((i64)b * p.G + g) * 4;
-        o[0] = mean;
-        o[1] = (float)(1.0 / sqrt(var + (double)p.eps));
-        o[2] = (float)sqrt(var);
-        o[3] = 0.f;
+        double *o = p.partials + (((i64)b * p.G + g) * kStatChunks + ch) * 2;
+        o[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        o[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
+}
+__global__ __launch_bounds__(64) void group_stats_final_kernel(const GroupStatsArgs p)
+{
+    const int bg = blockIdx.x; // b * G + g
+    const double *pp = p.partials + (i64)bg * kStatChunks * 2;
+    if (threadIdx.x != 0)
+        return;
+    double s = 0, q = 0;
+    for (int ch = 0; ch < kStatChunks; ++ch)
+        s += pp[2 * ch], q += pp[2 * ch + 1];
+    const double cnt = (double)p.rows * (p.C / p.G);
+    const double mean = s / cnt;
+    double var = (q - cnt * mean * mean) / (cnt - 1.0); // unbiased (Q3)
+    if (var < 0)
+        var = 0;
+    float *o = p.out + (i64)bg * 4;
+    o[0] = (float)mean;
+    o[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    o[2] = (float)sqrt(var);
+    o[3] = 0.f;
 }
 
 void launch_group_stats(const GroupStatsArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(group_stats_kernel, dim3(a.G, a.B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(group_stats_partial_kernel, dim3(kStatChunks, a.G, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(group_stats_final_kernel, dim3(a.G * a.B), dim3(64), 0, s, a);
 }
 
 // --------------------------------------------------------------------------- GroupNorm apply (+GELU | +GLU), crop, scale, residual
