@@ -64,6 +64,45 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
     return DMX_OK;
 }
 
+// EXPERIMENT switch: DMX_GEMM=bf16x3 routes the MFMA-bound igemm ops through the exact-split bf16 kernels
+bool split_gemm_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("DMX_GEMM");
+        return e && !strcmp(e, "bf16x3");
+    }();
+    return on;
+}
+// an op may use the split kernel when a kernel exists for its (tile, prologue, epilogue) and every weight it reads is the
+// exact sum of its two bf16 planes (true for tensors that come straight from the fp16 file; derived ones keep fp32)
+static bool split_ok(const dmx_model *m, const IGemm &g)
+{
+    if (!split_gemm_enabled() || !m->dWb || m->pm.blob.size() != m->blobFloats)
+        return false;
+    GemmArgs k{};
+    k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
+    k.Wb1 = k.Wb2 = m->dWb;
+    if (launch_igemm_split(g.cfg, k, nullptr, true) != 0)
+        return false;
+    const float *w = m->pm.blob.data() + g.w_w;
+    for (i64 i = 0; i < (i64)g.Np * g.Kp; ++i)
+    {
+        unsigned u;
+        std::memcpy(&u, &w[i], 4);
+        const unsigned h1 = u & 0xffff0000u;
+        float f1, f2;
+        std::memcpy(&f1, &h1, 4);
+        const float r = w[i] - f1;
+        unsigned ur;
+        std::memcpy(&ur, &r, 4);
+        ur &= 0xffff0000u;
+        std::memcpy(&f2, &ur, 4);
+        if (f1 + f2 != w[i])
+            return false;
+    }
+    return true;
+}
+
 int dmx_model_upload(dmx_model *m, const float *blob)
 {
     HIPCHK(hipSetDevice(m->device));
@@ -78,6 +117,28 @@ int dmx_model_upload(dmx_model *m, const float *blob)
         (void)hipFree(m->dW);
         m->dW = nullptr;
         return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
+    }
+    if (split_gemm_enabled())
+    {
+        // EXPERIMENT (igemm_split.hip): every blob element as two bf16 terms by truncation, w1 = top 16 bits of w,
+        // w2 = top 16 bits of (w - w1). Exact for fp16-representable values (11 significand bits); whether an op's weights
+        // ARE exact is checked per op when the plan is built (split_ok).
+        std::vector<unsigned short> planes(2 * m->blobFloats + 1024, 0);
+        for (size_t i = 0; i < m->blobFloats; ++i)
+        {
+            unsigned u;
+            std::memcpy(&u, &blob[i], 4);
+            const unsigned h1 = u & 0xffff0000u;
+            float f1, r;
+            std::memcpy(&f1, &h1, 4);
+            r = blob[i] - f1;
+            unsigned ur;
+            std::memcpy(&ur, &r, 4);
+            planes[i] = (unsigned short)(h1 >> 16);
+            planes[m->blobFloats + 512 + i] = (unsigned short)(ur >> 16);
+        }
+        HIPCHK(hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short)));
+        HIPCHK(hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     return DMX_OK;
 }
@@ -111,6 +172,8 @@ extern "C" void dmx_model_free(dmx_model *m)
     {
         (void)hipSetDevice(m->device);
         (void)hipFree(m->dW);
+        if (m->dWb)
+            (void)hipFree(m->dWb);
     }
     delete m;
 }
@@ -149,6 +212,9 @@ static Plan *get_plan(dmx_ctx *c, int batch)
         return it->second.get();
     auto p = std::make_unique<Plan>();
     build_plan(c->m->pm, c->seg, batch, *p);
+    for (Op &op : p->ops)
+        if (op.kind == OP_IGEMM)
+            op.g.split = split_ok(c->m, op.g) ? 1 : 0;
     Plan *raw = p.get();
     c->plans[batch] = std::move(p);
     return raw;
@@ -352,6 +418,14 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         k.M = (i64)g.B * g.P1 * g.P0;
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
+        k.Wb1 = k.Wb2 = nullptr;
+        if (g.split && c->m->dWb)
+        {
+            k.Wb1 = c->m->dWb + g.w_w;
+            k.Wb2 = c->m->dWb + c->m->blobFloats + 512 + g.w_w;
+            if (launch_igemm_split(g.cfg, k, s) == 0)
+                break;
+        }
         if ((g.cfg == kDirectCfg ? launch_dgemm(k, s) : launch_igemm(g.cfg, k, s)) != 0)
             return fail(DMX_ERR_ARG, "internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)", op.name.c_str(), g.cfg, g.pro,
                         g.epi);

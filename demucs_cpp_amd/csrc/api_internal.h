@@ -35,6 +35,7 @@ struct dmx_model
                             // can be replicated onto further devices (dmx_model_clone) without re-reading the file
     size_t blobFloats = 0;  // size of the packed weights (also when pm.blob has been released)
     float *dW = nullptr;
+    unsigned short *dWb = nullptr; // EXPERIMENT (DMX_GEMM=bf16x3): two bf16 planes of the blob, w = w1 + w2, each blobFloats long
     int device = 0;
 };
 // uploads `blob` (blobFloats floats) as the weights of `m` on m->device

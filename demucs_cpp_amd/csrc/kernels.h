@@ -43,6 +43,7 @@ struct GemmArgs
     const float *proStats, *proW, *proB;
     int G0;
     const float *Wt, *bias;
+    const unsigned short *Wb1, *Wb2; // bf16 planes of the weight blob (same element offsets as Wt), or null (igemm_split.hip)
     int N, Np;
     int epi, act;
     float *Y;
@@ -71,6 +72,8 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
 // returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;
 // dry = true only checks availability
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
+// EXPERIMENT (DMX_GEMM=bf16x3): the same tiles with exact bf16 operand splits on the bf16 matrix pipe; -1 = not available
+int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
 
 struct ReduceArgs
 {

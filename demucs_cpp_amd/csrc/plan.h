@@ -111,6 +111,7 @@ struct IGemm
     int trS, trOff;           // EPI_TRCONV: n = (r, co), r < trS; output position j = trS*p0 + r - trOff
                               // (k8/s4 with the 2-sample crop: 4, 2; v3's uncropped k8/s4: 4, 0; k4/s2: 2, 0)
     int cfg;                  // tile configuration index (engine)
+    int split;                // EXPERIMENT (DMX_GEMM=bf16x3, api.cpp): run on the exact-split bf16 kernel (igemm_split.hip)
 };
 
 struct StatsReduce
