@@ -20,6 +20,7 @@
 // igemm.hip's kernel; the accumulator layout of the 16x16 MFMAs does not depend on the operand type.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace dmx
 {
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 
     __shared__ u32x4 Ap0[3][BM][4], Ap1[3][BM][4];   // [plane][row][octet slot]
     __shared__ u32x4 Bp0[2][BRP][4], Bp1[2][BRP][4];
-    __shared__ int4 rowinfo[BM];         // b, p1, p0, group (-1: row >= M)
-    __shared__ float2 rsum[BM][WAVES_N]; // cross-wave row statistics
+    // (row info is recomputed where it is needed and the row-statistics scratch aliases the A image after the K loop:
+    // the two staging images are exactly 80 KB for the 128x128 tile, two workgroups = the CU's 160 KB)
+    float2(*rsum)[WAVES_N] = reinterpret_cast<float2(*)[WAVES_N]>(&Ap0[0][0][0]);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -83,14 +85,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
 
-    for (int r = tid; r < BM; r += 256)
-    {
+    // row r of the tile -> (b, p1, p0, group), -1 in .w beyond M: magic-number divisions (kernels.h FastDiv)
+    auto rowinfo_of = [&](int r) -> int4 {
         const i64 m = m0 + r;
         int4 ri = make_int4(0, 0, 0, -1);
         if (m < p.M)
         {
-            // magic-number divisions (three 64-bit software divides per row were a visible part of the
-            // per-tile prologue)
             const unsigned mu = (unsigned)m;
             const unsigned t = p.dP0.magic ? (__umulhi(mu, p.dP0.magic) >> p.dP0.shift) : (mu >> p.dP0.shift);
             const int p0 = (int)(mu - t * (unsigned)p.P0);
@@ -98,9 +98,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             const int p1 = (int)(t - b * (unsigned)p.P1);
             ri = make_int4((int)b, p1, p0, (int)b * p.G0 + (p.G0 > 1 ? p0 : 0));
         }
-        rowinfo[r] = ri;
-    }
-    __syncthreads();
+        return ri;
+    };
 
     // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slane`
     const int slane = tid % LPR, srow = tid / LPR;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < AR; ++i)
     {
-        const int4 ri = rowinfo[srow + i * RP];
+        const int4 ri = rowinfo_of(srow + i * RP);
         aRowOk[i] = ri.w >= 0;
         const int in1_0 = ri.y * p.stride1 - p.pad1;
         const int e0 = (ri.z * p.stride0 - p.pad0) * p.Cin;
@@ -164,8 +163,10 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     }
 
 
-    f32x4 aReg[AR], gW, gB;
-    u32x4 bReg[BR];
+    // two staging register sets: a tile is requested a whole iteration before it is written to LDS
+    f32x4 aRegS[2][AR], gWS[2], gBS[2];
+    u32x4 bRegS[2][BR];
+    unsigned maskHeldS[2] = {0u, 0u};
     const int nk = (p.Kp + 31) >> 5;
     // Sequential K walk, one tile = 16*KS consecutive k; this lane stages k = kl .. kl+3.
     // (s1, offb) = conv tap along axis 1 / offset inside its contiguous run, advanced per
@@ -303,33 +304,38 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < BR; ++i)
         bPtr[i] = bRowOk[i] ? (bPlane ? p.Wb2 : p.Wb1) + (bRow[i] - p.Wt) + bOct * 8 : reinterpret_cast<const unsigned short *>(p.zero);
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](auto setTag) {
+        constexpr int SET = decltype(setTag)::value;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            aReg[i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
+            aRegS[SET][i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
 #pragma unroll
         for (int i = 0; i < BR; ++i)
         {
-            bReg[i] = *reinterpret_cast<const u32x4 *>(bPtr[i]);
+            bRegS[SET][i] = *reinterpret_cast<const u32x4 *>(bPtr[i]);
             bPtr[i] += bRowOk[i] ? 32 : 0;
         }
         if (PRO == PRO_GN_GELU)
         {
-            gW = *reinterpret_cast<const f32x4 *>(addrG);
-            gB = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
+            gWS[SET] = *reinterpret_cast<const f32x4 *>(addrG);
+            gBS[SET] = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
         }
-        maskHeld = maskNext;
+        maskHeldS[SET] = maskNext;
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto setTag, int buf, int a0, int a1e, int b0, int b1e) {
+        constexpr int SET = decltype(setTag)::value;
+        const f32x4 gW = gWS[SET], gB = gBS[SET];
         u32x4(*Ap)[BM][4] = buf ? Ap1 : Ap0;
         u32x4(*Bp)[BRP][4] = buf ? Bp1 : Bp0;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
         {
-            f32x4 v = aReg[i];
+            if (i < a0 || i >= a1e)
+                continue;
+            f32x4 v = aRegS[SET][i];
             if (PRO != PRO_NONE)
             {
-                const bool ok = (maskHeld >> i) & 1u;
+                const bool ok = (maskHeldS[SET] >> i) & 1u;
                 if (PRO == PRO_AFFINE)
                 {
                     v.x = (v.x - aMean[i]) * aScale[i];
@@ -372,8 +378,10 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
         for (int i = 0; i < BR; ++i)
         {
+            if (i < b0 || i >= b1e)
+                continue;
             const int row = srow + i * RP;
-            Bp[bPlane][row][bOct ^ swz(row)] = bReg[i];
+            Bp[bPlane][row][bOct ^ swz(row)] = bRegS[SET][i];
         }
     };
 
@@ -384,68 +392,83 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
         for (int j = 0; j < WNF; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- pipeline (one barrier per K-tile, two staging register sets): iteration kt multiplies tile kt row fragment by row
+    // fragment; at its start it requests tile kt+2 into the register set whose contents went to LDS one iteration ago, and
+    // in its first row steps it writes tile kt+1 (requested a whole iteration earlier) into the other LDS image. A fragments
+    // are read one row step ahead.
+    const std::integral_constant<int, 0> set0{};
+    const std::integral_constant<int, 1> set1{};
     compute_addrs();
-    issue_loads();
+    issue_loads(set0);
     compute_addrs();
-    store_tiles(0);
+    issue_loads(set1);
+    compute_addrs(); // tile 2
+    store_tiles(set0, 0, 0, AR, 0, BR);
     __syncthreads();
-    int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
     const int fslot = kq ^ swz(l15);
-    for (int kt = 0; kt < nk; ++kt)
-    {
-        issue_loads(); // tile kt+1 (zero page beyond the end: no branch)
+    constexpr int SH = (WMF + 1) / 2; // row steps that store
+    auto iteration = [&](auto parTag) {
+        constexpr int PAR = decltype(parTag)::value; // tile kt lives in LDS image PAR and came from register set PAR
+        u32x4(*Ap)[BM][4] = PAR ? Ap1 : Ap0;
+        u32x4(*Bp)[BRP][4] = PAR ? Bp1 : Bp0;
+        issue_loads(parTag); // tile kt+2 (zero page beyond the end: no branch)
+        bf16x8 b1[WNF], b2[WNF], a1, a2, a3, n1, n2, n3;
+#pragma unroll
+        for (int j = 0; j < WNF; ++j)
         {
-            u32x4(*Ap)[BM][4] = cur ? Ap1 : Ap0;
-            u32x4(*Bp)[BRP][4] = cur ? Bp1 : Bp0;
-            bf16x8 a1[WMF], a2[WMF], a3[WMF], b1[WNF], b2[WNF];
+            const int r = wn * (WNF * 16) + j * 16 + l15;
+            b1[j] = __builtin_bit_cast(bf16x8, Bp[0][r][fslot]);
+            b2[j] = __builtin_bit_cast(bf16x8, Bp[1][r][fslot]);
+        }
+        {
+            const int r = wm * (WMF * 16) + l15;
+            a1 = __builtin_bit_cast(bf16x8, Ap[0][r][fslot]);
+            a2 = __builtin_bit_cast(bf16x8, Ap[1][r][fslot]);
+            a3 = __builtin_bit_cast(bf16x8, Ap[2][r][fslot]);
+        }
 #pragma unroll
-            for (int i = 0; i < WMF; ++i)
+        for (int i = 0; i < WMF; ++i)
+        {
+            if (i + 1 < WMF)
             {
-                const int r = wm * (WMF * 16) + i * 16 + l15;
-                a1[i] = __builtin_bit_cast(bf16x8, Ap[0][r][fslot]);
-                a2[i] = __builtin_bit_cast(bf16x8, Ap[1][r][fslot]);
-                a3[i] = __builtin_bit_cast(bf16x8, Ap[2][r][fslot]);
-            }
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-            {
-                const int r = wn * (WNF * 16) + j * 16 + l15;
-                b1[j] = __builtin_bit_cast(bf16x8, Bp[0][r][fslot]);
-                b2[j] = __builtin_bit_cast(bf16x8, Bp[1][r][fslot]);
+                const int r = wm * (WMF * 16) + (i + 1) * 16 + l15;
+                n1 = __builtin_bit_cast(bf16x8, Ap[0][r][fslot]);
+                n2 = __builtin_bit_cast(bf16x8, Ap[1][r][fslot]);
+                n3 = __builtin_bit_cast(bf16x8, Ap[2][r][fslot]);
             }
             // smallest terms first; operands swapped (weights as A, activations as B): the accumulator holds C^T
 #pragma unroll
-            for (int i = 0; i < WMF; ++i)
+            for (int j = 0; j < WNF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a3, acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a3[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WNF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a2, acc[i][j], 0, 0, 0);
+            if (i < SH) // tile kt+1: the other register set -> the other image
+                store_tiles(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1, i * AR / SH, (i + 1) * AR / SH, i * BR / SH, (i + 1) * BR / SH);
 #pragma unroll
-            for (int i = 0; i < WMF; ++i)
+            for (int j = 0; j < WNF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a1, acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a2[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WNF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a2, acc[i][j], 0, 0, 0);
+            if (i == WMF - 1)
+                compute_addrs(); // addresses of tile kt+3
 #pragma unroll
-            for (int i = 0; i < WMF; ++i)
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a1[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WMF; ++i)
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a2[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WMF; ++i)
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WNF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1, acc[i][j], 0, 0, 0);
+            a1 = n1, a2 = n2, a3 = n3;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        store_tiles(cur ^ 1);
-        compute_addrs();
         __syncthreads();
-        cur ^= 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2)
+    {
+        iteration(set0);
+        if (kt + 1 < nk)
+            iteration(set1);
     }
+    __syncthreads(); // (rsum aliases the A image)
 
     // ------------------------------------------------------------------ epilogue
     // The MFMAs were issued with the operands swapped (weights as A, activations as B), so each
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     for (int i = 0; i < WMF; ++i)
     {
         const int rl = wm * (WMF * 16) + i * 16 + l15;
-        const int4 ri = rowinfo[rl];
+        const int4 ri = rowinfo_of(rl);
         const bool rowOk = ri.w >= 0;
         const i64 m = m0 + rl;
         float s = 0.f, ss = 0.f;
@@ -730,6 +753,22 @@ int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_LINEAR)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_GLU)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_TRCONV)
+        // half / quarter-height siblings (few segments in flight): same column decomposition, same bits as their parents
+        DMX_CASE(15, 2, 2, 1, 4, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(15, 2, 2, 1, 4, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(15, 2, 2, 1, 4, PRO_NONE, EPI_GLU)
+        DMX_CASE(15, 2, 2, 1, 4, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(9, 2, 2, 2, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(9, 2, 2, 2, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(9, 2, 2, 2, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(9, 2, 2, 2, 2, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(16, 2, 2, 1, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(16, 2, 2, 1, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(16, 2, 2, 1, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(16, 2, 2, 1, 2, PRO_NONE, EPI_TRCONV)
+        DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_GLU)
+        DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_TRCONV)
     default:
         return -1;
     }

@@ -825,3 +825,56 @@ def test_cli_shards_over_dmx_devices_and_finish_modes(dmx, tmp_models, tmp_path)
         _, a = read_wav(str(tmp_path / "ft_one" / f"target_{i}_{names[i]}.wav"))
         _, b = read_wav(str(tmp_path / "ft_three" / f"target_{i}_{names[i]}.wav"))
         assert np.array_equal(a, b), ("ft", i)
+
+
+def test_split_bf16x3_experiment_matches_oracle_and_golden(tmp_models, golden_dir):
+    """EXPERIMENT, opt-in (DMX_GEMM=bf16x3, csrc/igemm_split.hip): the MFMA-bound convs / linears on the bf16 matrix pipe
+    with EXACT operand splits (a = a1 + a2 + a3, w = w1 + w2, fp32 accumulate). The switch is read once per process, so the
+    checks run in a child: fp64 golden (4- and 6-source), full-size segment with every tap against the oracle incl. the
+    local metrics, batch == singles bitwise, Demucs v3. The error against the fp64 model must not exceed the fp32 MFMA
+    path's by more than 10 % (measured: it is slightly smaller)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+import numpy as np, torch
+import oracle_lib as orc, parity_utils as pu
+from demucs_cpp_amd import binding as dmx
+orc.lib().orc_set_num_threads(min(32, os.cpu_count() or 1))
+m4, m6, m3 = sys.argv[1:4]
+res = {}
+for ns, path in ((4, m4), (6, m6)):
+    g = np.load(f"tests/golden/golden_seg_{ns}s.npz")
+    m = dmx.Model(path); ctx = dmx.Context(m, int(g["seg"]), 1)
+    res[f"fp64_{ns}"] = pu.relerr(ctx.segment(g["mix"]), g["out"])
+    ctx.close(); m.close()
+g = np.load("tests/golden/golden_seg_v3.npz")
+m = dmx.Model(m3); ctx = dmx.Context(m, int(g["seg"]), 1)
+res["fp64_v3"] = pu.relerr(ctx.segment(g["mix"]), g["out"])
+ctx.close(); m.close()
+mix = (0.1 * np.random.default_rng(4).standard_normal((2, 343980))).astype(np.float32)
+m = dmx.Model(m4); ctx = dmx.Context(m, 0, 3); om = orc.OracleModel(m4)
+errs, out, ref = pu.compare_segment(ctx, om, mix)  # asserts the local metrics
+res["oracle_worst"] = max(errs.values())
+mixes = np.stack([mix, mix[::-1].copy(), 0.5 * mix])
+d_mix = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).cuda()
+d_out = torch.zeros((3, 4, 2, 343980), device="cuda")
+torch.cuda.synchronize()
+ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), 3); ctx.synchronize()
+res["batch_bitwise"] = bool(np.array_equal(d_out.cpu().numpy()[0], out))
+print("RESULT " + json.dumps(res))
+'''
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        r = subprocess.run([sys.executable, "-c", code, tmp_models[4], tmp_models[6], tmp_models[3]], cwd=ROOT,
+                           env=dict(os.environ, DMX_GEMM=mode), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        import json
+        outs[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    s, f = outs["bf16x3"], outs["f32"]
+    assert s["batch_bitwise"] and f["batch_bitwise"]
+    assert s["oracle_worst"] < TOL
+    for k in ("fp64_4", "fp64_6", "fp64_v3"):
+        assert s[k] < TOL and s[k] <= 1.1 * f[k] + 1e-8, (k, s[k], f[k])
+    print("split vs fp32 errors:", s, f)
