@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--no-track", action="store_true")
+    ap.add_argument("--no-split-probe", action="store_true",
+                    help="skip the secondary measurement of the opt-in exact-split bf16 path (DMX_GEMM=bf16x3, a child process)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: TEST MODE ONLY - several ranks share GPU 0 and the gather goes through host memory, to "
                          "exercise the N > 1 control flow (double buffering, flush, overlap-add of all ranks' segments) on a "
@@ -392,6 +394,21 @@ def main():
             orc.use_openblas(False)
         om.close()
 
+    # EXPERIMENT, never `value`: the same step with the MFMA-bound convs / linears on the bf16 matrix pipe through exact
+    # operand splits (csrc/igemm_split.hip). The switch is read once per process: measured in a child.
+    split_probe = None
+    if rank == 0 and world == 1 and not args.no_split_probe and os.environ.get("DMX_GEMM", "f32") != "bf16x3":
+        import subprocess
+
+        cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(B), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--model", args.model, "--no-cpu-baseline", "--no-track", "--no-single", "--no-roofline", "--no-split-probe"]
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, DMX_GEMM="bf16x3"), capture_output=True, text=True, timeout=600)
+            child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            split_probe = (child["value"], child["config"]["ms_per_segment"], child["config"]["outputs_finite"])
+        except Exception as e:  # the probe is informational
+            print(f"[bench] split probe failed: {e}", file=sys.stderr)
+
     if rank == 0:
         audio_s = n_track / 44100.0 * args.steps          # seconds of track produced
         seg_s = nseg_total * SEG_SECONDS * args.steps        # seconds of audio processed (segments overlap by 25 %)
@@ -426,6 +443,11 @@ def main():
                        "track_strong_wall_s": None if track_strong is None else min(track_strong["wall_s"]),
                        "track_strong_ranks": None if track_strong is None else track_strong["ranks"],
                        "ms_per_segment": round(elapsed / args.steps / B * 1e3, 3), "outputs_finite": finite,
+                       "gemm_path": os.environ.get("DMX_GEMM", "f32") + (" (EXPERIMENT: exact bf16x3 operand split, fp32 accumulate)"
+                                                                         if os.environ.get("DMX_GEMM") == "bf16x3" else " MFMA (v_mfma_f32_16x16x4_f32)"),
+                       # opt-in experiment (DMX_GEMM=bf16x3), same step in a child process; NOT the headline
+                       "experiment_bf16x3_split_xRT": None if split_probe is None else split_probe[0],
+                       "experiment_bf16x3_split_ms_per_segment": None if split_probe is None else split_probe[1],
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        # the latency point against the same roofline: 340.2 GFLOP in one call vs the fp32 MFMA peak

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-24}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single --no-track"
+CMD="python $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single --no-track --no-split-probe"
 rocprofv3 -L 2>/dev/null | grep -oE "\b(TA_[A-Z_]+|TCP_[A-Z_0-9]+|TCC_[A-Z_0-9]+|TD_[A-Z_]+)\b" | sort -u | tr '\n' ' ' | cut -c1-3000 > $R/gpurun_out/pmc/mem_counters.txt
 p=0
 for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
