@@ -725,6 +725,12 @@ def test_shim_is_reentrant_and_eigen_overloads_match(dmx, tmp_models):
     assert r.returncode == 0 and "OK reentrant 4 threads" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([exe_e, "eigen", tmp_models[4], "300000"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK eigen overloads" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the reference's wasm glue call sequence (src_wasm/demucs.cpp:100-140) on the Eigen-typed names, 6-source model
+    r = subprocess.run([exe_e, "wasm", tmp_models[6], "100000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK wasm call sequence" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # namespace demucscpp_v3 (src/model.hpp:668-1415) and the cross-family "bad magic" behaviour
+    r = subprocess.run([exe, "v3", tmp_models[3], "200000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK v3 shim" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_single_segment_graph_replay_is_bit_identical(dmx, tmp_models, monkeypatch):
