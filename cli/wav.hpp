@@ -21,6 +21,13 @@
 
 namespace wavio
 {
+// frames of the file a converted track came from: the stems are cut back to it on the way out (the round trip
+// ceil(ceil(N L/M) M/L) is up to a few samples longer than N, and a stem must line up with its source file)
+inline int64_t &native_frames()
+{
+    static int64_t n = -1;
+    return n;
+}
 inline int resample_device()
 {
     const char *d = getenv("DMX_DEVICE");
@@ -181,6 +188,7 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         }
         std::cout << "Converted " << rate << " Hz -> " << demucscpp::SUPPORTED_SAMPLE_RATE << " Hz on the GPU: " << n441 << " samples" << std::endl;
         out = std::move(conv);
+        native_frames() = (int64_t)N;
     }
     return true;
 }
@@ -202,7 +210,7 @@ inline bool write_audio_file(const float *interleaved, int64_t N, const std::str
             return false;
         }
         interleaved = conv.data();
-        N = n2;
+        N = native_frames() >= 0 ? std::min<int64_t>(n2, native_frames()) : n2; // sample-aligned with the source file
     }
     FILE *f = fopen(filename.c_str(), "wb");
     if (!f)

@@ -144,6 +144,6 @@ def test_cli_accepts_48k_input_with_dmx_resample(dmx, tmp_path):
     for i, name in enumerate(["drums", "bass", "other", "vocals"]):
         rate, stem = read_wav(str(out_dir / f"target_{i}_{name}.wav"))
         want = dmx.resample(ref[i], 44100, 48000)
-        assert rate == 48000 and stem.shape == want.shape
-        assert abs(stem.shape[1] - n48) <= 2  # ceil(ceil(n 147/160) 160/147): the round trip may add a sample
-        assert np.array_equal(stem, want)
+        # ceil(ceil(n 147/160) 160/147) may exceed n by a sample or two: the stems are cut back to the file's own length
+        assert rate == 48000 and stem.shape == (2, n48) and want.shape[1] >= n48
+        assert np.array_equal(stem, want[:, :n48])
