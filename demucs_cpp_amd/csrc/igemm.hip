@@ -111,17 +111,18 @@ __device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_
 // small pieces BETWEEN the eight 16-MFMA groups of tile t (pinned with sched_barrier), so a wave's
 // instruction stream is a uniform MFMA-dominated mix with no long matrix-idle stretch.
 template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN, bool IL>
-__global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
 {
     static_assert(!IL || KS == 2, "interleaved loop is written for 2 k-chunks per tile");
+    constexpr int NT = WAVES_M * WAVES_N * 64; // 256 threads; 512 for the double-height tile (4 x 2 waves, ONE workgroup per CU)
     constexpr int BM = WAVES_M * WMF * 16;
     constexpr int BN = WAVES_N * WNF * 16;
     constexpr int LPR = 4 * KS;              // lanes per staged row: one float4 each = the row's 16*KS floats (full 128-B lines at KS=2)
-    constexpr int RP = 256 / LPR;            // rows staged per pass
+    constexpr int RP = NT / LPR;             // rows staged per pass
     constexpr int RPB = 16 / LPR;            // rows per 256 B of the LDS image (swizzle period)
     constexpr int AR = BM / RP;              // A rows staged per thread (row = tid/LPR + i*RP)
     constexpr int BR = (BN + RP - 1) / RP;   // B rows staged per thread
-    static_assert(WAVES_M * WAVES_N == 4, "256 threads");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
     static_assert(BM % RP == 0, "BM multiple of the staging pass");
     static_assert((RP / RPB) % LPR == 0 && (16 / RPB) % LPR == 0, "swizzle term constant per lane");
     constexpr bool DIRECT = DMX_IGEMM_DIRECT && IL && PRO == PRO_NONE; // global -> LDS without registers
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
 
-    for (int r = tid; r < BM; r += 256)
+    for (int r = tid; r < BM; r += NT)
     {
         const i64 m = m0 + r;
         int4 ri = make_int4(0, 0, 0, -1);
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel
         if (wantStats)
         {
             __syncthreads();
-            for (int r = tid; r < BM; r += 256)
+            for (int r = tid; r < BM; r += NT)
             {
                 const i64 m = m0 + r;
                 if (m < p.M)
@@ -976,16 +977,16 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
         if (linOn && is_linear<WM_, WN_, MF, NF, KS, PRO, EPI>(a))
         {
             if (CAN_IL && ilOn)
-                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, a);
             else
-                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, false>), dim3(blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, false>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, a);
             return;
         }
     }
     if (CAN_IL && ilOn)
-        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, CAN_IL>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, CAN_IL>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, false, false>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, a);
 }
 
 // Instantiated (tile, prologue, epilogue) combinations = exactly what plan.cpp emits for the
@@ -1010,6 +1011,12 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_ONLY)
         DMX_CASE(0, 2, 2, 4, 4, DMX_BIG_KS, PRO_GN_GELU, EPI_STATS_FACT) // Demucs v3 level 3: hidden 96 -> 98 factor columns
+        // cfg 17: 256x128 = the double-height sibling of 0 (4 x 2 waves of 64x64, one workgroup per CU: 6 instead of 8
+        // staged float4 per lane and K-tile; same column decomposition, bit-identical). Experiment, DMX_TALL=1.
+        DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_GLU)
+        DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_TRCONV)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)

@@ -102,6 +102,8 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
         return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
+    if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 1 && M >= 256 * 256)
+        return 17; // experiment: the double-height tile for launches of at least one full round of 256-row tiles
     if (const char *e = getenv("DMX_FORCE_HALF")) // experiment: 1 = one halving step for every op, 2 = two
     {
         for (int k = atoi(e); k > 0 && half_cfg(best, stat) >= 0; --k)

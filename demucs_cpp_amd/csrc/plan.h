@@ -309,8 +309,9 @@ static const TileCfg kTileCfgs[] = {
     // leave most CUs with a single workgroup)
     {32, 128},  // 15  of 7 (2 x 2 waves, 1 x 4 fragments: the column decomposition of 0 and 7, row statistics identical)
     {32, 64},   // 16  of 9
+    {256, 128}, // 17  double-height sibling of 0 (8 waves, one workgroup per CU); experiment behind DMX_TALL=1
 };
-static const int kNumTileCfgs = 17;
+static const int kNumTileCfgs = 18;
 static const int kDirectCfg = 8;
 // cfg -> its half-height sibling (-1: none); stat = the op writes row statistics
 int half_cfg(int cfg, bool stat);

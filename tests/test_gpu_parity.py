@@ -8,6 +8,7 @@ relative to the reference tensor's max-abs < 1e-4 (= the reference's own NEAR_TO
 /root/reference/test/test_layers.cpp:708, test_dsp.cpp:13). Observed ~1e-6.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -686,12 +687,7 @@ def test_reference_benchmark_file_through_track_and_cli_vs_oracle(dmx, tmp_model
     ctx.close(); m.close(); om.close()
 
 
-@pytest.mark.parametrize("gain", [0.25, 4.0])
-def test_weight_scale_sweep_vs_oracle(gain, dmx, tmp_path, oracle_threads):
-    """Where in DESIGN.md section 3's error envelope does a checkpoint with larger / smaller weights sit? Every conv / linear
-    / attention weight of the default synthetic model scaled by `gain` (norm affines, biases and LayerScale untouched):
-    activations between norms change by up to gain^depth while every norm brings them back - the regime trained
-    checkpoints live in. Full-size segment, all taps, global + local metrics."""
+def _gain_model(tmp_path, gain):
     from demucs_cpp_amd.weights import synth_weights, write_model, tensor_catalogue
     w = synth_weights(4, 0)
     for name, _ in tensor_catalogue(4):
@@ -700,12 +696,46 @@ def test_weight_scale_sweep_vs_oracle(gain, dmx, tmp_path, oracle_threads):
             w[name] = (w[name].astype(np.float32) * gain).astype(np.float16)
     path = str(tmp_path / f"gain{gain}-4s.bin")
     write_model(path, w, 4)
+    return w, path
+
+
+@pytest.mark.parametrize("gain", [0.25, 0.5])
+def test_weight_scale_sweep_vs_oracle(gain, dmx, tmp_path, oracle_threads):
+    """Where in DESIGN.md section 3's error envelope does a checkpoint with larger / smaller weights sit? Every conv / linear
+    / attention weight of the default synthetic model scaled by `gain` (norm affines, biases and LayerScale untouched).
+    Gains <= 1 are well conditioned in fp32: full-size segment, all taps, global + local metrics at the usual tolerance."""
+    _, path = _gain_model(tmp_path, gain)
     mix = (0.1 * np.random.default_rng(18).standard_normal((2, SEG_FULL))).astype(np.float32)
     m = dmx.Model(path); ctx = dmx.Context(m, 0, 1); om = orc.OracleModel(path)
     errs, out, ref = pu.compare_segment(ctx, om, mix)
     bad = {k: v for k, v in errs.items() if not (v < TOL)}
     assert not bad, bad
     print(f"gain {gain}: worst global tap error {max(errs.values()):.2e}, local {pu.LAST_LOCAL}")
+    ctx.close(); m.close(); om.close()
+
+
+@pytest.mark.parametrize("gain", [2.0, 4.0])
+def test_weight_scale_sweep_ill_conditioned_side_vs_fp64(gain, dmx, tmp_path, oracle_threads):
+    """Gains > 1 make THE MODEL ill conditioned in fp32, not the kernels: the encoders have no normalisation, activations
+    grow 16x per level (x_3 ~ 2e4 at gain 4), the GLU gates saturate to hard switches, and the fp32 ORACLE itself is
+    9.5e-4 (gain 2) / 0.27 (gain 4) away from the fp64 model of tests/golden/make_golden.py - any fp32 implementation,
+    the reference included, lands that far from any other. The meaningful statement there is relative: the product is
+    no further from the exact (fp64) result than the fp32 restatement of the reference is. Reduced segment (the fp64
+    torch model runs on the host)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    w, path = _gain_model(tmp_path, gain)
+    seg = 20000
+    mix = (0.1 * np.random.default_rng(18).standard_normal((2, seg))).astype(np.float32)
+    exact = mg.segment_forward(w, 4, mix, {})
+    m = dmx.Model(path); ctx = dmx.Context(m, seg, 1); om = orc.OracleModel(path)
+    got = ctx.segment(mix)
+    ref = om.segment(mix)
+    e_hip, e_orc, e_pair = pu.relerr(got, exact), pu.relerr(ref, exact), pu.relerr(got, ref)
+    print(f"gain {gain}: HIP vs fp64 {e_hip:.2e}, oracle vs fp64 {e_orc:.2e}, HIP vs oracle {e_pair:.2e}")
+    assert np.isfinite(got).all()
+    assert e_orc > TOL, "the premise: fp32 itself is outside the tolerance here"
+    assert e_hip < 3 * e_orc + 1e-5
     ctx.close(); m.close(); om.close()
 
 
