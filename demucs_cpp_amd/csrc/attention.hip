@@ -469,7 +469,11 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
     const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B, wg64 = (long)((a.Tq + 63) / 64) * a.H * a.B;
     const double costBig = (double)((wg128 + 511) / 512), costSmall = 0.6 * (double)((wg64 + 511) / 512);
     static const int forceSmall = getenv("DMX_ATT_SMALL") ? atoi(getenv("DMX_ATT_SMALL")) : 0; // experiment: 64-query workgroups everywhere
-    const bool big = !forceSmall && costBig <= costSmall;
+    static const int forceBig = getenv("DMX_ATT_BIG") ? atoi(getenv("DMX_ATT_BIG")) : 0; // experiment: 128-query workgroups everywhere
+    // Below two full rounds of 128-query workgroups the launch is latency-bound, not matrix-bound, and the 64-query
+    // shape (twice the waves for the same work) wins whatever the round count says: measured at 1 / 2 / 4 segments
+    // 1.12 / 1.78 / 3.17 ms (64) vs 1.39 / 2.05 / 3.32 ms (128) for the ten attention launches of a plan run.
+    const bool big = forceBig || (!forceSmall && wg128 >= 1024 && costBig <= costSmall);
     if (a.hs != 64 && a.hs != 48)
         abort();
     a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);
