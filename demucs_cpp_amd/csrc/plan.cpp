@@ -97,8 +97,12 @@ int half_cfg(int cfg, bool stat)
 int refine_cfg(int cfg, i64 M, int N, bool stat)
 {
     auto cost = [&](int c, int depth) {
-        const i64 T = ((M + kTileCfgs[c].BM - 1) / kTileCfgs[c].BM) * ((N + kTileCfgs[c].BN - 1) / kTileCfgs[c].BN);
-        const i64 n = (T + 255) / 256;
+        // the XCD-aware tile map (igemm.hip) deals ROW tiles round-robin to the 8 XCDs and runs all column tiles of a row
+        // tile on that XCD: the busiest XCD holds ceil(tilesM / 8) x tilesN workgroups for its 32 CUs. (Counting T / 256
+        // instead missed e.g. 84 x 6 tiles = 11 row tiles on four of the XCDs = 66 workgroups for 64 slots: a second
+        // round for two stragglers, decoder.0.rewrite at 4 segments 617 us with 128x128 vs 428 us with 64x128.)
+        const i64 tm = (M + kTileCfgs[c].BM - 1) / kTileCfgs[c].BM, tn = (N + kTileCfgs[c].BN - 1) / kTileCfgs[c].BN;
+        const i64 n = (((tm + 7) / 8) * tn + 31) / 32;
         return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
