@@ -16,6 +16,7 @@
 //   * the same prologues / epilogues as igemm.hip (plan.h), same row-statistics contract.
 // Semantics are specified by plan.h and tests/cpu_interp.cpp exactly like igemm.hip.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace dmx
 {
@@ -445,6 +446,147 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const Fast
     }
 }
 
+// --------------------------------------------------------------------------- DConv K1: ONE read per input row
+// K1 = Conv1d(C -> C/8, k3, dilation d) along TIME. The three taps of an output row are the input rows at t-d, t, t+d,
+// so the generic kernel above fetches every input row three times through L1 / the texture addresser, which is what
+// bounds it (TA busy 76-84 %, 2.5-3.6 TB/s of algorithmic bytes). Here every LANE ROW of a wave
+// walks the time axis and keeps the fragments of rows t-d .. t+d in a register ring (2d+2 slots: the window plus one
+// row in flight); each step loads only row t+d+1:
+//   frequency branch [B][T][F][C]: the 16 lane rows are 16 consecutive bins, all at the same t (a chunk of the walk
+//                                  re-reads 2d halo rows);
+//   time branch      [B][L][C]:    the 16 lane rows are 16 consecutive sub-chunks of `len` time steps each, lane row r
+//                                  walks [t0 + r len, t0 + (r+1) len) (its halo rows are its neighbours' first / last rows).
+// MFMA order (tap, k, sub-step) and the epilogue are those of dgemm_kernel: every output bit is unchanged, whatever
+// the chunk length (chosen per launch for occupancy).
+template <int SEG0, int DIL, bool TIME>
+__global__ __launch_bounds__(256) void dgemm_k1_ring_kernel(const GemmArgs p, const int len, const int nChunks, const int nFb)
+{
+    constexpr int NV4 = SEG0 / 16;
+    constexpr int RING = 2 * DIL + 2;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, h = lane >> 4;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int T = p.P1, F = p.P0; // TIME: F == 1
+    const i64 rowLen = (i64)F * SEG0;
+
+    f32x4 Bv[3][NV4]; // weights, MFMA A operand (operands swapped: C^T), lane = column n = l15
+    {
+        const bool nOk = l15 < p.Np;
+        const float *w = p.Wt + (i64)(nOk ? l15 : 0) * p.Kp;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < NV4; ++j)
+                Bv[s][j] = *reinterpret_cast<const f32x4 *>(nOk ? w + s * SEG0 + 16 * j + 4 * h : p.zero);
+    }
+    const int n = 4 * h;
+    const float4 biasv = ld4z(p.bias + n, n < p.N, p.zero);
+
+    const int ntask = p.B * nChunks * nFb;
+    for (int task = gwave; task < ntask; task += nwaves)
+    {
+        const int fb = task % nFb, ck = (task / nFb) % nChunks, b = task / (nFb * nChunks);
+        const int f = TIME ? 0 : fb * 16 + l15;
+        const bool fOk = f < F;
+        // this lane row walks [tl0, tl1); the loop below runs `len` steps for the whole wave
+        const int tl0 = TIME ? (ck * 16 + l15) * len : ck * len;
+        const int tl1 = min(T, tl0 + len);
+        const float *xb = p.X + (i64)b * p.xBS + (i64)(fOk ? f : 0) * SEG0 + 4 * h;
+        f32x4 ring[RING][NV4];
+        auto load_row = [&](int slot, int t) {
+            const bool ok = fOk && t >= 0 && t < T && t < tl1 + DIL; // rows past the walk's halo are never used
+            const float *src = ok ? xb + (i64)t * rowLen : p.zero;
+#pragma unroll
+            for (int j = 0; j < NV4; ++j)
+                ring[slot][j] = *reinterpret_cast<const f32x4 *>(ok ? src + 16 * j : src);
+        };
+#pragma unroll
+        for (int i = 0; i <= 2 * DIL; ++i)
+            load_row(i, tl0 - DIL + i);
+        const int steps = TIME ? len : min(T, tl0 + len) - tl0; // wave-uniform
+        for (int ub = 0; ub < steps; ub += RING)
+        {
+#pragma unroll
+            for (int u = 0; u < RING; ++u)
+            {
+                if (ub + u < steps) // wave-uniform
+                {
+                    const int t = tl0 + ub + u;
+                    load_row((u + 2 * DIL + 1) % RING, t + DIL + 1);
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int j = 0; j < NV4; ++j)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Bv[s][j][c], ring[(u + s * DIL) % RING][j][c], acc, 0, 0, 0);
+                    const bool rOk = fOk && t < tl1;
+                    const i64 em = ((i64)b * T + t) * F + f;
+                    float sm = 0.f, ss = 0.f;
+                    if (rOk && n < p.N)
+                    {
+                        float4 v = make_float4(acc[0] + biasv.x, acc[1] + biasv.y, acc[2] + biasv.z, acc[3] + biasv.w);
+                        if (p.act)
+                            v = make_float4(dgelu(v.x), dgelu(v.y), dgelu(v.z), dgelu(v.w));
+                        *reinterpret_cast<float4 *>(p.Y + em * p.ldy + n) = v;
+                        sm += (v.x + v.y) + (v.z + v.w);
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
+                    if (p.rowstat)
+                    {
+                        sm += __shfl_xor(sm, 16);
+                        ss += __shfl_xor(ss, 16);
+                        sm += __shfl_xor(sm, 32);
+                        ss += __shfl_xor(ss, 32);
+                        if (h == 0 && rOk)
+                            *reinterpret_cast<float2 *>(p.rowstat + em * 2) = make_float2(sm, ss); // NB == 1
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int SEG0>
+static void launch_k1_ring(const GemmArgs &a, hipStream_t s)
+{
+    const bool time = a.P0 == 1;
+    const int nFb = time ? 1 : (a.P0 + 15) / 16;
+    // length of a lane row's walk: long enough to amortise the 2d halo rows, short enough for >= ~4 waves per SIMD
+    const i64 target = 4096;
+    const i64 lanesRows = time ? (i64)a.B * a.P1 / 16 : (i64)a.B * nFb * a.P1; // walk steps summed over all waves
+    int len = (int)((lanesRows + target - 1) / target);
+    len = len < 8 ? 8 : (len > 56 ? 56 : len);
+    const int nChunks = time ? (a.P1 + 16 * len - 1) / (16 * len) : (a.P1 + len - 1) / len;
+    const i64 ntask = (i64)a.B * nChunks * nFb;
+    int blocks = (int)((ntask + 3) / 4);
+    if (blocks > 256 * 8)
+        blocks = 256 * 8;
+#define DMX_K1(D, TM) hipLaunchKernelGGL((dgemm_k1_ring_kernel<SEG0, D, TM>), dim3(blocks), dim3(256), 0, s, a, len, nChunks, nFb)
+    if (time && a.dil1 == 1)
+        DMX_K1(1, true);
+    else if (time)
+        DMX_K1(2, true);
+    else if (a.dil1 == 1)
+        DMX_K1(1, false);
+    else
+        DMX_K1(2, false);
+#undef DMX_K1
+}
+// K1 shapes the ring kernels cover: taps along axis 1; >= 16 bins per time step (frequency branch) or one (time branch)
+static bool k1_ring_ok(const GemmArgs &a)
+{
+    const char *e = getenv("DMX_K1_RING"); // read per call: A/B runs inside one process (tools/gpu_k1ring.sh); 0 = off, 2 = frequency branch only, 3 = time branch always
+    const int on = e ? atoi(e) : 1;
+    // time branch: measured at 42 / 1 segments per call, C = 96 (L = 21499): 153 -> 110 us / 15.6 -> 17.5 us; C = 48 (L = 85995):
+    // 223 -> 257 us / 12.7 -> 11.5 us (a lane row's 32-byte output pieces are scattered `len` rows apart, and short walks
+    // re-read up to half of their rows as halo): only the C = 96 shape, and only when the walk is >= 12 steps long
+    const bool timeOk = a.P0 == 1 && on != 2 && (on == 3 || (a.seg0 == 96 && (i64)a.B * a.P1 >= 12ll * 16 * 4096));
+    return on && a.pro == PRO_NONE && a.epi == EPI_LINEAR && a.S1 == 3 && a.N <= 16 && (a.P0 >= 16 || timeOk) && a.L0 == a.P0 &&
+           a.L1 == a.P1 && a.stride0 == 1 && a.stride1 == 1 && a.pad0 == 0 && a.pad1 == a.dil1 && (a.dil1 == 1 || a.dil1 == 2) &&
+           a.seg0 == a.Cin && a.NB == 1 && !a.res;
+}
+
 #ifndef DMX_DG_PIPE
 #define DMX_DG_PIPE -1 // -1: per-shape choice of the launch table; 0/1/2 force one pipeline (experiments)
 #endif
@@ -474,9 +616,15 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
         if (!dry)                                                             \
             launch_d<NF_, S1_, SEG_, PRO_, EPI_, PIPE_>(a, s);                \
         return 0;
+    if (k1_ring_ok(a) && (a.seg0 == 48 || a.seg0 == 96))
+    {
+        if (!dry)
+            a.seg0 == 48 ? launch_k1_ring<48>(a, s) : launch_k1_ring<96>(a, s);
+        return 0;
+    }
     switch (NF * 1000000 + a.S1 * 100000 + a.seg0 * 100 + a.pro * 10 + a.epi)
     {
-        // DConv k1: Conv1d(C -> C/8, k3): C = 48, 96
+        // DConv k1: Conv1d(C -> C/8, k3): C = 48, 96 (time branch; the frequency branch takes the ring kernel above)
         DMX_D(1, 3, 48, PRO_NONE, EPI_LINEAR, 0)
         DMX_D(1, 3, 96, PRO_NONE, EPI_LINEAR, 1)
         // DConv k2 / k3: hidden 8 (C=48) / 12 (C=96) -> 2C, statistics / final
