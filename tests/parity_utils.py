@@ -148,3 +148,22 @@ def compare_segment(ctx, omodel, mix, b=0, taps=True, local=True):
         assert_local_parity(out, ref, what="segment output")
         LAST_LOCAL["out_block"], LAST_LOCAL["out_min_stem_sdr_db"] = local_errors(out, ref)
     return errs, out, ref
+
+
+def fp64_segment_forward(w, n_sources, mix):
+    """The fp64 torch model of tests/golden/make_golden.py on (weights dict, mix (2, seg)). That script sets torch's
+    DEFAULT dtype to float64 when imported (and relies on it): set it for the call only and restore what was there -
+    a float64 default leaking into the other tests turns their `torch.zeros(..., device="cuda")` buffers into doubles."""
+    import os
+    import sys
+    import torch
+    prev = torch.get_default_dtype()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    try:
+        import make_golden as mg
+        torch.set_default_dtype(torch.float64)
+        return mg.segment_forward(w, n_sources, mix, {})
+    finally:
+        torch.set_default_dtype(prev)

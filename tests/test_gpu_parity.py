@@ -722,12 +722,10 @@ def test_weight_scale_sweep_ill_conditioned_side_vs_fp64(gain, dmx, tmp_path, or
     the reference included, lands that far from any other. The meaningful statement there is relative: the product is
     no further from the exact (fp64) result than the fp32 restatement of the reference is. Reduced segment (the fp64
     torch model runs on the host)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import make_golden as mg
     w, path = _gain_model(tmp_path, gain)
     seg = 20000
     mix = (0.1 * np.random.default_rng(18).standard_normal((2, seg))).astype(np.float32)
-    exact = mg.segment_forward(w, 4, mix, {})
+    exact = pu.fp64_segment_forward(w, 4, mix)
     m = dmx.Model(path); ctx = dmx.Context(m, seg, 1); om = orc.OracleModel(path)
     got = ctx.segment(mix)
     ref = om.segment(mix)

@@ -93,9 +93,7 @@ def test_weight_gain_2_is_an_fp32_conditioning_limit_not_a_plan_error(interp, tm
     tests/golden/make_golden.py - the un-normalised encoders grow activations 4x per level and the GLU gates saturate -
     and the interpreted product plan is no further from the exact result than the oracle is (GPU counterpart:
     test_weight_scale_sweep_ill_conditioned_side_vs_fp64)."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import make_golden as mg
+    import parity_utils as pu
     from demucs_cpp_amd.weights import synth_weights, write_model, tensor_catalogue
     w = synth_weights(4, 0)
     for name, _ in tensor_catalogue(4):
@@ -105,7 +103,7 @@ def test_weight_gain_2_is_an_fp32_conditioning_limit_not_a_plan_error(interp, tm
     path = str(tmp_path / "gain2-4s.bin")
     write_model(path, w, 4)
     mix = (0.1 * np.random.default_rng(18).standard_normal((1, 2, 10000))).astype(np.float32)
-    exact = mg.segment_forward(w, 4, mix[0], {})
+    exact = pu.fp64_segment_forward(w, 4, mix[0])
     out = run(interp, path, mix)[0]
     m = orc.OracleModel(path)
     ref = m.segment(mix[0])
