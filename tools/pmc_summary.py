@@ -21,7 +21,7 @@ def kernel_class(name: str) -> str:
         wm, wn, mf, nf = (int(x) for x in m.groups())
         return f"igemm_split_{wm * mf * 16}x{wn * nf * 16}"
     for key, cls in (("lstm_kernel", "lstm"), ("local_attn_kernel", "local_attn"), ("group_stats", "group_stats"), ("gn_act_kernel", "gn_act"),
-                     ("dgemm_kernel", "dgemm_direct"), ("attention_kernel", "attention"), ("track_stats", "track_stats"),
+                     ("dgemm_k1_ring_kernel", "dgemm_k1_ring"), ("dgemm_kernel", "dgemm_direct"), ("attention_kernel", "attention"), ("track_stats", "track_stats"),
                      ("track_gather", "track_gather"), ("track_ola", "track_ola"), ("istft_ola", "istft_ola"), ("istft", "istft"), ("stft", "stft"),
                      ("stats_", "stats_reduce"), ("layernorm", "layernorm"), ("gn_apply", "gn_apply"), ("ola_kernel", "ola")):
         if key in name:
