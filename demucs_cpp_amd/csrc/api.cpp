@@ -500,8 +500,37 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_LSTM:
     {
         const Lstm &l = op.lstm;
+        // The cooperative kernel spins on its partner workgroups, which is safe for ONE launch (in-order dispatch: every
+        // recurrence's partners are resident before any later recurrence's) but not for launches of SEVERAL contexts that
+        // share a device: at 42 segments a launch keeps 144 workgroups spinning, the device holds 512, and the fourth
+        // concurrent launch could leave every resident workgroup waiting for a partner that has no slot (the bounded
+        // spin would then turn it into an error, not a hang). LSTM launches of one device therefore form a lane: each
+        // waits for the previous one's completion event, whatever stream or context it came from. (Graph captures - batches
+        // below 8, at most 48 spinning workgroups per launch - stay outside: a capture cannot wait on a foreign event.)
+        struct LstmLane
+        {
+            std::mutex mu;
+            hipEvent_t ev = nullptr;
+            bool recorded = false;
+        };
+        static LstmLane lanes[64];
+        LstmLane *lane = !c->capturing && c->m->device >= 0 && c->m->device < 64 ? &lanes[c->m->device] : nullptr;
+        std::unique_lock<std::mutex> laneLock;
+        if (lane)
+        {
+            laneLock = std::unique_lock<std::mutex>(lane->mu);
+            if (!lane->ev)
+                HIPCHK(hipEventCreateWithFlags(&lane->ev, hipEventDisableTiming));
+            if (lane->recorded)
+                HIPCHK(hipStreamWaitEvent(s, lane->ev, 0));
+        }
         if (launch_lstm(LstmArgs{a(l.xproj), w(l.whh_w), a(l.out), a(l.sync), c->dStatus, l.B, l.T, l.H}, s) != 0)
             return fail(DMX_ERR_ARG, "internal error: no LSTM kernel for op %s (H = %d)", op.name.c_str(), l.H);
+        if (lane)
+        {
+            HIPCHK(hipEventRecord(lane->ev, s));
+            lane->recorded = true;
+        }
         break;
     }
     case OP_LOCAL_ATTN:
@@ -604,7 +633,9 @@ static int run_plan(dmx_ctx *c, int batch)
             hipGraph_t g = nullptr;
             std::lock_guard<std::mutex> graphLock(g_graphMutex);
             HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->capturing = true;
             const int rc = enqueue_plan(c, p, true);
+            c->capturing = false;
             const hipError_t e = hipStreamEndCapture(c->stream, &g);
             if (rc != DMX_OK || e != hipSuccess)
             {

@@ -98,6 +98,7 @@ struct dmx_ctx
     int graphMode = 1; // env DMX_GRAPH: 0 off, 1 (default) capture the two-stream plans of small batches into HIP graphs
     int fuseIstft = 1; // env DMX_FUSE_ISTFT=0: ISTFT and overlap-add as two kernels through the `frames` tensor (A/B)
     int graphBatch = 0; // batch size the cached graphs were captured for
+    bool capturing = false; // enqueue_plan runs inside hipStreamBeginCapture (no cross-context event waits may be recorded)
     GraphKey lastKey{nullptr, nullptr, nullptr};
     bool haveLastKey = false;
     ~dmx_ctx();

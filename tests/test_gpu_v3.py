@@ -203,3 +203,24 @@ def test_v3_cli_mt_and_sharded_devices(dmx, tmp_models, tmp_path):
         outs.append([read_wav(str(od / f"target_{i}_{nm}.wav"))[1] for i, nm in enumerate(names)])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_v3_concurrent_contexts_at_full_batches_share_the_lstm_lane(dmx, tmp_models):
+    """Four contexts on ONE GPU, each running a 42-segment batch at the same time (engine with logical devices
+    [0, 0, 0, 0]): every launch of the cooperative LSTM kernel keeps 144 workgroups spinning on their partners and the
+    device holds 512, so four unordered launches could starve each other's partners of slots (the bounded spin would
+    report an error). csrc/api.cpp orders the LSTM launches of a device in a lane; the result must be the single-context
+    track, bit for bit, twice in a row."""
+    stride = 257985
+    nseg = 4 * 42
+    n = (nseg - 1) * stride + 1000
+    audio = (0.1 * np.random.default_rng(61).standard_normal((2, n))).astype(np.float32)
+    m = dmx.Model(tmp_models[3]); ctx = dmx.Context(m, 0, 42)
+    assert ctx.track_geometry(n, 0)[1] == nseg
+    ref = ctx.track(audio, 0)
+    ctx.close(); m.close()
+    eng = dmx.Engine([tmp_models[3]], [0, 0, 0, 0], max_batch=42)
+    for _ in range(2):
+        got = eng.track(audio, [0])
+        assert np.array_equal(got, ref)
+    eng.close()
