@@ -62,7 +62,7 @@ PEAK_TFLOPS_FP32_MFMA = 157.3
 MODEL_FLOPS_4S = 340.2e9  # algorithmic FLOPs per segment (SURVEY.md §8d / BASELINE.md §3)
 
 
-def pmc_traffic(kernel_class, batch):
+def pmc_traffic(kernel_class, batch, model="4s"):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes
     (profiles/rNN_traffic.json, written by tools/traffic_json.py from separate FETCH_SIZE and
     WRITE_SIZE passes over this same workload; gfx950 corrections applied there). The counters cannot be
@@ -70,7 +70,8 @@ def pmc_traffic(kernel_class, batch):
     the same batch size."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    # one file per workload: rNN_traffic.json is htdemucs-4s, rNN_traffic_<model>.json any other model (none committed => null)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json" if model == "4s" else f"r*_traffic_{model}.json")))
     if not files:
         return None, None
     try:
@@ -349,7 +350,7 @@ def main():
         kname, (ms, fl, by, cnt) = dom
         tot_ms = sum(v[0] for v in by_kernel.values())
         achieved = fl / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(kname, B)
+        traffic, traffic_src = pmc_traffic(kname, B, args.model)
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": traffic,
