@@ -789,6 +789,32 @@ def test_single_segment_graph_replay_is_bit_identical(dmx, tmp_models, monkeypat
     ctx.close(); m.close()
 
 
+@pytest.mark.parametrize("which", [4, 6, 3])
+def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp_models, monkeypatch):
+    """DConv K1 with one read per input row (csrc/dgemm.hip dgemm_k1_ring_kernel: a register ring along the time axis;
+    DESIGN.md 7.3) against the generic direct kernel it replaces: DMX_K1_RING=0 (off), 1 (the product's rule) and 3 (ring
+    on the time branch as well, whatever the size) must give identical bits - full-size segments (walks of 8-56 steps,
+    ragged last walk) and a short odd length (T = 9 frames: a walk shorter than the ring)."""
+    import torch
+    m = dmx.Model(tmp_models[which])
+    S = m.n_sources
+    for B, seg in ((3, SEG_FULL), (2, 9 * 1024 + 2)):
+        mix = (0.1 * np.random.default_rng(90 + B).standard_normal((B, seg, 2))).astype(np.float32)
+        outs = []
+        for mode in ("0", "1", "3"):
+            monkeypatch.setenv("DMX_K1_RING", mode)
+            ctx = dmx.Context(m, seg, B)
+            d_mix = torch.from_numpy(mix).cuda()
+            d_out = torch.zeros((B, S, 2, seg), device="cuda", dtype=torch.float32)
+            ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+            ctx.synchronize()
+            outs.append(d_out.cpu().numpy())
+            ctx.close()
+        assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1e-3
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    m.close()
+
+
 def test_run_to_run_determinism_stress():
     """tools/stress_determinism.py at 12 repeats: the same batch (24, 4, 1 segments; 6-source model at 12) through the
     hot path again and again, every output bit-identical to the first. (This is the test that caught a missing
