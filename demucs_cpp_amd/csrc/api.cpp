@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 
 using namespace dmx;
@@ -536,7 +537,23 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_LOCAL_ATTN:
     {
         const LocalAttn &l = op.la;
-        if (launch_local_attn(LocalAttnArgs{a(l.qkvd), a(l.out), l.B, l.T, l.H, l.ld}, s) != 0)
+        // default: the flash attention kernel with the decay penalty (fp32 MFMA; csrc/attention.hip LOC);
+        // DMX_LOCAL_ATTN=valu: the reference-order VALU kernel of csrc/v3.hip (A/B, and what tests/cpu_interp.cpp specifies)
+        static const bool valu = getenv("DMX_LOCAL_ATTN") && std::string(getenv("DMX_LOCAL_ATTN")) == "valu";
+        const int hd = l.H / 4;
+        int rc = -1;
+        if (!valu)
+        {
+            AttnArgs t{};
+            t.q = a(l.qkvd), t.k = a(l.qkvd) + l.H, t.v = a(l.qkvd) + 2 * l.H, t.o = a(l.out);
+            t.ldq = t.ldk = t.ldv = l.ld, t.ldo = l.H;
+            t.qB = t.kB = t.vB = (i64)l.T * l.ld, t.oB = (i64)l.T * l.H;
+            t.B = l.B, t.Tq = t.Tk = l.T, t.H = 4, t.hs = hd;
+            t.scale = 1.0f / std::sqrt((float)hd);
+            t.decay = a(l.qkvd) + 3 * l.H, t.ldd = l.ld, t.dB = (i64)l.T * l.ld;
+            rc = launch_attention_local(t, s);
+        }
+        if (rc != 0 && launch_local_attn(LocalAttnArgs{a(l.qkvd), a(l.out), l.B, l.T, l.H, l.ld}, s) != 0)
             return fail(DMX_ERR_ARG, "internal error: no LocalState kernel for op %s (T = %d, H = %d)", op.name.c_str(), l.T, l.H);
         break;
     }

@@ -81,8 +81,11 @@ __device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_
 #endif
 }
 
-template <int HS, int QF>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
+// LOC: LocalState attention of Demucs v3 (/root/reference/src/layers.cpp:533-721): the score of (query s, key t) gets the
+// decay penalty sum_n -(n+1) |t-s| / 2 * sigmoid(d_n(s)) / 2 = -|t-s| g(s) (one scalar per query and head), the diagonal
+// is set to -100 (not masked out), then the same softmax over the keys and the same weighted sum of the content.
+template <int HS, int QF, bool LOC = false>
+__global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const AttnArgs p)
 {
     constexpr int DQ = HS / 4;  // dim quads
     constexpr int DF = HS / 16; // dim fragments
@@ -138,6 +141,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
         {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(Q + (i64)min(qr, p.Tq - 1) * p.ldq + 16 * kk + 4 * h4);
             qf[f][kk] = make_float4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs); // rows >= Tq: duplicates, never stored
+        }
+    }
+    // LOC: decay slope of this lane's query in the exp2 domain, and the query's own index (the diagonal)
+    float gq[QF];
+    int qrow[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+    {
+        gq[f] = 0.f;
+        qrow[f] = q0 + 16 * f + l15;
+        if constexpr (LOC)
+        {
+            const float *dl = p.decay + (i64)b * p.dB + (i64)min(qrow[f], p.Tq - 1) * p.ldd + head * 4;
+            float g = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                g += ((float)(n + 1) * 0.5f) * (0.5f / (1.0f + __expf(-dl[n])));
+            gq[f] = g * 1.44269504088896340736f;
         }
     }
 
@@ -264,6 +285,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs p)
         constexpr bool MASK = decltype(maskTag)::value;
         if (DMX_ABL_ATT_NOSM)
             return;
+        if constexpr (LOC)
+        {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int key = t * KT + 16 * kf + 4 * h4 + r;
+                    const float dist = fabsf((float)(key - qrow[f]));
+                    sT[f][kf][r] = key == qrow[f] ? -100.0f * 1.44269504088896340736f : sT[f][kf][r] - dist * gq[f];
+                }
+        }
         if constexpr (MASK)
         {
 #pragma unroll
@@ -493,6 +526,23 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
         else
             hipLaunchKernelGGL((attention_kernel<48, 1>), grid, dim3(256), 0, s, a);
     }
+}
+
+int launch_attention_local(const AttnArgs &a0, hipStream_t s)
+{
+    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
+    AttnArgs a = a0;
+    a.xcdMap = xcdMap;
+    if (!a.decay || (a.hs != 48 && a.hs != 96))
+        return -1;
+    a.nQt = (unsigned)((a.Tq + 63) / 64); // 64-query workgroups: T = 336 / 168, a handful of key tiles per query tile
+    const unsigned nbh = (unsigned)(a.B * a.H);
+    const dim3 grid(xcdMap ? 8u * ((nbh + 7u) / 8u) * a.nQt : nbh * a.nQt);
+    if (a.hs == 48)
+        hipLaunchKernelGGL((attention_kernel<48, 1, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((attention_kernel<96, 1, true>), grid, dim3(256), 0, s, a);
+    return 0;
 }
 
 } // namespace dmx

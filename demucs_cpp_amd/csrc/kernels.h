@@ -127,9 +127,17 @@ struct AttnArgs
     float scale;
     unsigned nQt; // query tiles per (batch, head) (filled by launch_attention)
     int xcdMap;   // 1: all query tiles of one (batch, head) on ONE XCD (its K/V stay in that XCD's L2)
+    // LocalState attention of Demucs v3 (launch_attention_local): decay logits of query s, head h, term n at
+    // decay[b * dB + s * ldd + 4 h + n]; null for the transformer's attention
+    const float *decay;
+    int ldd;
+    i64 dB;
 };
 
 void launch_attention(const AttnArgs &a, hipStream_t s);
+// Demucs v3 LocalState (src/layers.cpp:533-721) on the same flash kernel: scores + decay penalty, diagonal = -100;
+// head dims 48 / 96. Returns -1 for other shapes.
+int launch_attention_local(const AttnArgs &a, hipStream_t s);
 
 struct IstftArgs
 {
