@@ -884,7 +884,7 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
     case OP_LSTM:
         R(op.lstm.xproj, (i64)op.lstm.B * op.lstm.T * 8 * op.lstm.H);
         Wr(op.lstm.out, (i64)op.lstm.B * op.lstm.T * 2 * op.lstm.H);
-        Wr(op.lstm.sync, lstm_sync_floats(op.lstm.B, op.lstm.H));
+        Wr(op.lstm.sync, lstm_xchg_floats(op.lstm.B, op.lstm.T, op.lstm.H));
         break;
     case OP_LOCAL_ATTN:
         R(op.la.qkvd, (i64)op.la.B * op.la.T * op.la.ld);
@@ -944,6 +944,14 @@ i64 lstm_sync_floats(int B, int H)
     // x 8 bytes {value, tag}
     const i64 nbg = (B + 15) / 16;
     return 2 * nbg * 2 * (i64)H * 16 * 2;
+}
+i64 lstm_xchg_floats(int B, int T, int H)
+{
+    // EXPERIMENT (DMX_LSTM_XCHG=x4): the 4-byte exchange image [2 directions x batch groups of 16][T][H][16] floats,
+    // sentinel-filled by the launcher; never smaller than the granule area (either form may be selected at run time)
+    const i64 nbg = (B + 15) / 16;
+    const i64 x = 2 * nbg * (i64)T * H * 16;
+    return x > lstm_sync_floats(B, H) ? x : lstm_sync_floats(B, H);
 }
 
 void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
@@ -1029,7 +1037,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
     const i64 aLxp = b.alloc(B * rowsH * 8), aLl0 = b.alloc(B * rowsH * 2), aLl1 = b.alloc(B * rowsH * 2);
     const i64 aLqkvd = b.alloc((i64)B * std::max((i64)T * (3 * 192 + 16), (i64)T5 * (3 * 384 + 16)));
     const i64 aLu = b.alloc((i64)B * std::max((i64)T * 1536, (i64)T5 * 3072));
-    const i64 aLsync = b.alloc(lstm_sync_floats(B, 384));
+    const i64 aLsync = b.alloc(std::max(lstm_xchg_floats(B, T, 192), lstm_xchg_floats(B, T5, 384)));
     const i64 aStG = b.alloc((i64)B * 4 * 4), aStGt = b.alloc((i64)B * 4 * 4);
     const i64 aGsScr = b.alloc((i64)B * 4 * 32 * 4), aGsScrT = b.alloc((i64)B * 4 * 32 * 4); // chunk partials (doubles), per stream
     // decoders 0 / 1, tdecoder 0

@@ -221,6 +221,7 @@ struct Lstm
     int B, T, H;
 };
 i64 lstm_sync_floats(int B, int H);
+i64 lstm_xchg_floats(int B, int T, int H); // >= lstm_sync_floats: the 4-byte exchange image [groups][T][H][16] (experiment)
 // LocalState attention core (/root/reference/src/layers.cpp:533-721), heads = 4, 4 decay rates.
 // qkvd: [B][T][ld] = [query H | key H | content H | decay logits 16] per position (one OP_IGEMM).
 // dots(t, s) = q_s . k_t / sqrt(H/4) - sum_n (n+1) |t-s| / 2 * sigmoid(d[s][4h+n]) / 2, diagonal = -100;

@@ -4,6 +4,7 @@
 //   /root/reference/src/layers.hpp:125-225 (generalized_group_norm), src/lstm.cpp:68-147 (lstm_forward),
 //   src/layers.cpp:533-721 (local_attention).
 #include "kernels.h"
+#include <string>
 
 namespace dmx
 {
@@ -302,28 +303,165 @@ __global__ __launch_bounds__(64 * NW) void lstm_kernel(const LstmArgs p)
     }
 }
 
+// EXPERIMENT (DMX_LSTM_XCHG=x4): 4-byte values in a sentinel-filled image X[group][t][unit][column], written once per
+// (t, unit, column): no tags, no re-arming. The launcher fills the image with 0xFFFFFFFF (a NaN no arithmetic produces), a
+// value is published by ONE agent-scope 4-byte store, the partners poll 8 bytes = two columns of a unit at a time (a
+// dword is either the sentinel or final, so tearing is harmless). Half the bytes and half the loads of the granule form.
 template <int H, int FR, int NW>
-static void launch_lstm_t(const LstmArgs &a, hipStream_t s)
+__global__ __launch_bounds__(64 * NW) void lstm_x4_kernel(const LstmArgs p)
+{
+    constexpr int UW = 4 * FR, UWG = NW * UW, P = H / UWG, HP = H + 4, NJ = H / 16;
+    constexpr int UQ = H / NW, NPOLL = UQ / 8;
+    static_assert(H % UWG == 0 && UQ % 8 == 0, "whole sweeps");
+    __shared__ float hs[2][16][HP];
+    constexpr unsigned SENT = 0xFFFFFFFFu;
+    const int nGroups = 2 * ((p.B + 15) / 16);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = xcd + 8 * (j / P), slot = j % P;
+    if (g >= nGroups)
+        return;
+    const int dir = g & 1, bg = g >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int bcol = bg * 16 + l15;
+    const bool valid = bcol < p.B;
+    const int ub = slot * UWG + wave * UW;
+    f32x4 wreg[FR][NJ];
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+    {
+        const float *wrow = p.whh + ((i64)dir * 4 * H + 4 * (ub + 4 * f) + l15) * H + 4 * kq;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+            wreg[f][jj] = *reinterpret_cast<const f32x4 *>(wrow + 16 * jj);
+    }
+    gu32 *X = (gu32 *)p.gran + (i64)g * p.T * H * 16; // [t][unit][column]
+    // poll positions of this lane: unit = wave UQ + 8 n + lane / 8, columns 2 cp, 2 cp + 1. Lanes whose columns lie beyond
+    // the batch re-read pair 0 (column 0 always exists) - the loads stay unconditional - and keep zeros
+    const int cp = lane & 7, pu0 = wave * UQ + (lane >> 3);
+    const int nValid = min(16, p.B - bg * 16);
+    const bool v0 = 2 * cp < nValid, v1 = 2 * cp + 1 < nValid;
+    const bool chkHi = v0 ? v1 : nValid > 1; // does the high dword of the pair this lane reads get published?
+    const int cpr = v0 ? cp : 0;
+    float cst[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+        cst[f] = 0.f;
+    for (int step = 0; step < p.T; ++step)
+    {
+        const int t = dir ? p.T - 1 - step : step;
+        f32x4 acc[FR];
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+        {
+            acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (valid)
+                acc[f] = *reinterpret_cast<const f32x4 *>(p.xproj + ((i64)bcol * p.T + t) * 8 * H + (i64)dir * 4 * H + 4 * (ub + 4 * f + kq));
+        }
+        if (step > 0)
+        {
+            const gu64 *src = (const gu64 *)(X + ((i64)(step - 1) * H + pu0) * 16 + 2 * cpr);
+            unsigned long long hv[NPOLL];
+            unsigned spins = 0;
+            for (;;)
+            {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NPOLL; ++n)
+                {
+                    hv[n] = __hip_atomic_load(src + n * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // 8 units further
+                    ok &= (unsigned)hv[n] != SENT && (!chkHi || (unsigned)(hv[n] >> 32) != SENT);
+                }
+                if (__all(ok))
+                    break;
+                if (++spins > (1u << 24))
+                {
+                    if (lane == 0)
+                        __hip_atomic_store((gu32 *)p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float(*hb)[HP] = hs[step & 1];
+#pragma unroll
+            for (int n = 0; n < NPOLL; ++n)
+            {
+                hb[2 * cp][pu0 + 8 * n] = v0 ? __uint_as_float((unsigned)hv[n]) : 0.f;
+                hb[2 * cp + 1][pu0 + 8 * n] = v1 ? __uint_as_float((unsigned)(hv[n] >> 32)) : 0.f;
+            }
+            __syncthreads();
+            f32x4 acc2[FR];
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                acc2[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+            {
+                const f32x4 hq = *reinterpret_cast<const f32x4 *>(&hb[l15][16 * jj + 4 * kq]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int f = 0; f < FR; ++f)
+                    {
+                        if ((c & 1) == 0)
+                            acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[f][jj][c], hq[c], acc[f], 0, 0, 0);
+                        else
+                            acc2[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[f][jj][c], hq[c], acc2[f], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                acc[f] += acc2[f];
+        }
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+        {
+            const float ig = lstm_sigmoid(acc[f][0]), fg = lstm_sigmoid(acc[f][1]), gg = lstm_tanh(acc[f][2]), og = lstm_sigmoid(acc[f][3]);
+            const float cn = fg * cst[f] + ig * gg;
+            cst[f] = cn;
+            const float h = og * lstm_tanh(cn);
+            const int unit = ub + 4 * f + kq;
+            if (valid)
+            {
+                if (step + 1 < p.T)
+                    __hip_atomic_store(X + ((i64)step * H + unit) * 16 + l15, __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.out[((i64)bcol * p.T + t) * 2 * H + (i64)dir * H + unit] = h;
+            }
+        }
+    }
+}
+
+template <int H, int FR, int NW>
+static void launch_lstm_t(const LstmArgs &a, hipStream_t s, bool x4)
 {
     constexpr int P = H / (4 * FR * NW);
     const int nGroups = 2 * ((a.B + 15) / 16);
     const unsigned blocks = 8u * P * (unsigned)((nGroups + 7) / 8);
-    hipLaunchKernelGGL((lstm_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
+    if (x4)
+        hipLaunchKernelGGL((lstm_x4_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
+    else
+        hipLaunchKernelGGL((lstm_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
 }
 
 int launch_lstm(const LstmArgs &a, hipStream_t s)
 {
+    static const bool x4 = getenv("DMX_LSTM_XCHG") && std::string(getenv("DMX_LSTM_XCHG")) == "x4"; // experiment
+    if (x4)
+    {
+        const size_t nGroups = 2 * (size_t)((a.B + 15) / 16);
+        if (hipMemsetAsync(a.gran, 0xFF, nGroups * a.T * a.H * 16 * sizeof(float), s) != hipSuccess)
+            return -1;
+    }
     // tags of an earlier launch must never satisfy a poll of this one
-    if (hipMemsetAsync(a.gran, 0, (size_t)lstm_sync_floats(a.B, a.H) * sizeof(float), s) != hipSuccess)
+    else if (hipMemsetAsync(a.gran, 0, (size_t)lstm_sync_floats(a.B, a.H) * sizeof(float), s) != hipSuccess)
         return -1;
     // workgroup shape (env DMX_LSTM_WAVES = 4 | 8, default 4): 4 waves = ONE wave per SIMD, i.e. the 32-cycle fp32 MFMAs of
     // a step are not shared with a second wave (the recurrence is latency-bound: a step cannot start before the
     // previous one's h has crossed the chip); the price is twice the workgroups polling the same granules
     static const int nw = getenv("DMX_LSTM_WAVES") ? atoi(getenv("DMX_LSTM_WAVES")) : 4;
     if (a.H == 192)
-        nw == 8 ? launch_lstm_t<192, 1, 8>(a, s) : launch_lstm_t<192, 1, 4>(a, s);
+        nw == 8 ? launch_lstm_t<192, 1, 8>(a, s, x4) : launch_lstm_t<192, 1, 4>(a, s, x4);
     else if (a.H == 384)
-        nw == 8 ? launch_lstm_t<384, 1, 8>(a, s) : launch_lstm_t<384, 1, 4>(a, s);
+        nw == 8 ? launch_lstm_t<384, 1, 8>(a, s, x4) : launch_lstm_t<384, 1, 4>(a, s, x4);
     else
         return -1;
     return 0;
