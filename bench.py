@@ -38,7 +38,7 @@ Extra objects on the JSON line:
   roofline     : dominant kernel (by device time) measured live with HIP events on the stream
                  it runs on (dmx_debug_profile), algorithmic FLOPs / duration vs the fp32 MFMA
                  peak 157.3 TFLOP/s (MI355X_MICROARCH.md); traffic = PMC HBM bytes (null unless
-                 profiles/ holds a counter pass)
+                 profiles/ holds a counter pass of the same model and batch)
   cpu_baseline : the CPU oracle (oracle/, a from-scratch port of the reference algorithm; the reference itself
                  needs Eigen and cannot be built here) timed on this box's host cores on ONE full segment, 1 warm-up +
                  median of 3, rank 0 at N = 1 only; `openblas_*` keys: the same port with its GEMMs routed through the
