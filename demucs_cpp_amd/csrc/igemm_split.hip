@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             ++tapC;
         }
     const float *addrA[AR], *addrB[BR], *addrG = p.zero;
-    unsigned maskNext = 0, maskHeld = 0;
+    unsigned maskNext = 0;
     i64 stepA[AR], stepB[BR]; // LIN: per-row advance (0 for rows that stay on the zero page)
     bool linInit = false;
     // addresses of the next tile to fetch, in two halves (the interleaved loop slots them between MFMA groups):
