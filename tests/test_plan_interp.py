@@ -180,3 +180,22 @@ def test_tile_choice_keeps_the_column_tiling_at_every_batch_size(ns, interp, tmp
                 big = -(-M // TILES[rcfg][0]) * -(-N // TILES[rcfg][1])
                 assert big <= 3 * 512, (name, b, big)  # only launches that would not fill the chip a few times over
     assert shrunk > 20  # one and two segments per call do use the small tiles
+
+
+def test_tile_choice_counts_workgroups_per_xcd(interp, tmp_models):
+    """The igemm tile map deals ROW tiles round-robin to the 8 XCDs (all column tiles of a row tile on one XCD), so the
+    cost model counts the workgroups of the busiest XCD: decoder.0.rewrite at 4 segments is 84 x 6 tiles of 128x128 =
+    11 row tiles on four of the XCDs = 66 workgroups for 64 slots; measured 617 us against 428 us with the 64x128 sibling
+    (DESIGN.md 7.1). The double-height experiment tile (cfg 17) is never chosen without DMX_TALL."""
+    interp.interp_plan_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    interp.interp_create_plan.restype = ctypes.c_void_p
+    interp.interp_create_plan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]
+    assert "DMX_TALL" not in os.environ
+    for b, want in ((4, 7), (42, 0)):
+        h = interp.interp_create_plan(tmp_models[4].encode(), 343980, b)
+        buf = ctypes.create_string_buffer(1 << 18)
+        assert interp.interp_plan_dump(h, buf, 1 << 18) > 0
+        interp.interp_free(h)
+        ops = {ln.split()[0]: ln.split() for ln in buf.value.decode().splitlines()}
+        assert int(ops["decoder.0.rewrite"][1]) == want, (b, ops["decoder.0.rewrite"])
+        assert all(int(o[1]) != 17 for o in ops.values())
