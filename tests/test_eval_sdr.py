@@ -91,24 +91,27 @@ def test_checkpoint_to_sdr_pipeline_on_a_random_init_hub_checkpoint(tmp_path):
 
 
 @pytest.mark.gpu
-def test_real_weights_sdr_matches_reference_scores(tmp_path):
-    """Opt-in: DMX_REAL_WEIGHTS = a htdemucs PyTorch checkpoint (.th) or a converted ggml-model-htdemucs-4s-f16.bin,
-    DMX_MUSDB_TRACK = directory with mixture.wav + {drums,bass,other,vocals}.wav of 'Zeno - Signs' (MUSDB18-HQ test).
-    Runs the CLI with the shift offset of SDR_scores.md (1337) and requires every target within +-0.1 dB of the
-    reference's own C++ numbers (/root/reference/.github/SDR_scores.md:16-20). Until this has run somewhere, parity of
-    conv / GEMM / attention with the Eigen reference stays "partial" (DESIGN.md section 3)."""
-    weights, track = os.environ.get("DMX_REAL_WEIGHTS"), os.environ.get("DMX_MUSDB_TRACK")
+@pytest.mark.parametrize("family", ["htdemucs", "hdemucs_mmi"])
+def test_real_weights_sdr_matches_reference_scores(family, tmp_path):
+    """Opt-in: DMX_REAL_WEIGHTS (htdemucs) / DMX_REAL_WEIGHTS_V3 (hdemucs_mmi) = a PyTorch checkpoint (.th) or a converted
+    ggml-model-*-f16.bin, DMX_MUSDB_TRACK = directory with mixture.wav + {drums,bass,other,vocals}.wav of 'Zeno - Signs'
+    (MUSDB18-HQ test). Runs the CLI with the shift offset of SDR_scores.md (1337) and requires every target within
+    +-0.1 dB of the reference's own C++ numbers (/root/reference/.github/SDR_scores.md:16-20 for demucs.cpp, :82-86 for
+    demucs_v3.cpp). Until this has run somewhere, parity of conv / GEMM / attention / LSTM with the Eigen reference stays
+    "partial" (DESIGN.md section 3)."""
+    v3 = family == "hdemucs_mmi"
+    weights, track = os.environ.get("DMX_REAL_WEIGHTS_V3" if v3 else "DMX_REAL_WEIGHTS"), os.environ.get("DMX_MUSDB_TRACK")
     if not weights or not track:
-        pytest.skip("DMX_REAL_WEIGHTS / DMX_MUSDB_TRACK not set (no checkpoints or MUSDB18-HQ in this environment)")
+        pytest.skip("DMX_REAL_WEIGHTS[_V3] / DMX_MUSDB_TRACK not set (no checkpoints or MUSDB18-HQ in this environment)")
     model = weights
     if weights.endswith(".th"):
-        model = str(tmp_path / "ggml-model-htdemucs-4s-f16.bin")
+        model = str(tmp_path / ("ggml-model-hdemucs_mmi-v3-f16.bin" if v3 else "ggml-model-htdemucs-4s-f16.bin"))
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convert_pth_to_dmc.py"), weights, model])
-    exe = os.path.join(ROOT, "cli", "demucs.cpp.main")
+    exe = os.path.join(ROOT, "cli", "demucs_v3.cpp.main" if v3 else "demucs.cpp.main")
     out_dir = tmp_path / "stems"
     env = dict(os.environ, DMX_SHIFT_OFFSET="1337")
     subprocess.check_call([exe, model, os.path.join(track, "mixture.wav"), str(out_dir)], env=env)
     refs, ests = eval_sdr.load_dirs(track, str(out_dir))
     got = eval_sdr.track_sdr(refs, ests)
-    for name, want in eval_sdr.SDR_SCORES_MD_CPP_4S.items():
+    for name, want in (eval_sdr.SDR_SCORES_MD_CPP_V3 if v3 else eval_sdr.SDR_SCORES_MD_CPP_4S).items():
         assert abs(got[name] - want) <= 0.1, (name, got[name], want)

@@ -30,6 +30,7 @@ TARGETS = ["drums", "bass", "other", "vocals", "guitar", "piano"]  # target_{i}_
 SDR_SCORES_MD_CPP_4S = {"vocals": 8.370, "drums": 10.002, "bass": 4.021, "other": 7.469}      # .github/SDR_scores.md:16-20
 SDR_SCORES_MD_CPP_6S = {"vocals": 8.395, "drums": 9.922, "bass": 4.523, "other": 0.167}       # :38-42
 SDR_SCORES_MD_CPP_FT = {"vocals": 8.679, "drums": 10.480, "bass": 4.590, "other": 7.370}      # :56-60
+SDR_SCORES_MD_CPP_V3 = {"vocals": 8.332, "drums": 9.285, "bass": 3.668, "other": 7.130}       # :82-86 (hdemucs_mmi, demucs_v3.cpp)
 
 
 def read_wav(path: str):
