@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_
 // small pieces BETWEEN the eight 16-MFMA groups of tile t (pinned with sched_barrier), so a wave's
 // instruction stream is a uniform MFMA-dominated mix with no long matrix-idle stretch.
 template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN, bool IL>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF == 8 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
 {
     static_assert(!IL || KS == 2, "interleaved loop is written for 2 k-chunks per tile");
     constexpr int NT = WAVES_M * WAVES_N * 64; // 256 threads; 512 for the double-height tile (4 x 2 waves, ONE workgroup per CU)
@@ -996,6 +996,8 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
 {
     if (a.M >= (1ll << 31) - 256)
         return -1; // 32-bit row arithmetic in the kernel prologue
+    if (cfg == 19) // 256x128, four waves of 128x64, linear layers only (igemm_lin256.hip)
+        return launch_igemm_lin256(a, s, dry);
 #define DMX_CASE(cfgid, WM_, WN_, MF, NF, KS, PRO, EPI) \
     case (cfgid * 100 + PRO * 10 + EPI):                \
         if (!dry)                                       \
@@ -1017,6 +1019,12 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_GLU)
         DMX_CASE(17, 4, 2, 4, 4, 2, PRO_NONE, EPI_TRCONV)
+        // cfg 18: 256x128 with FOUR waves of 128x64 and 16-deep K-tiles (two workgroups per CU stay independent; 12 instead
+        // of 16 fragment reads and 6 instead of 8 staged float4 per 128 MFMAs). Experiment, DMX_TALL=2; plain loop only.
+        DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_SCALE_RES)
+        DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_GLU)
+        DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_TRCONV)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)

@@ -72,6 +72,8 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
 // returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;
 // dry = true only checks availability
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
+// linear layers on a 256x128 tile with four waves of 128x64 (igemm_lin256.hip); -1 when the op is not a plain linear layer
+int launch_igemm_lin256(const GemmArgs &a, hipStream_t s, bool dry = false);
 // EXPERIMENT (DMX_GEMM=bf16x3): the same tiles with exact bf16 operand splits on the bf16 matrix pipe; -1 = not available
 int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
 

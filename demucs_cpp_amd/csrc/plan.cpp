@@ -57,8 +57,10 @@ int choose_cfg(i64 M1, int N, bool paired)
         return 2;
     if (N % 128 != 0 && N % 96 == 0)
         return 2;
-    i64 tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-    return tiles128 >= 256 ? 0 : 7;
+    // the 2 x 4 family: refine_cfg walks down its chain 0 -> 7 -> 15 / 9 -> 16 from the ACTUAL row count (round 3: the
+    // nominal-batch choice between 0 and 7 kept the time-branch linears on 64x128 tiles even at 42 segments)
+    (void)M;
+    return 0;
 }
 
 int half_cfg(int cfg, bool stat)
@@ -106,6 +108,8 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
         return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
+    if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 2 && M >= 256 * 256)
+        return 18;
     if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 1 && M >= 256 * 256)
         return 17; // experiment: the double-height tile for launches of at least one full round of 256-row tiles
     if (const char *e = getenv("DMX_FORCE_HALF")) // experiment: 1 = one halving step for every op, 2 = two
@@ -197,6 +201,18 @@ struct Builder
         g.Np = rup(g.N, 16);
         g.xBatchStride = (i64)g.L1 * g.L0 * g.Cin;
         g.cfg = refine_cfg(choose_cfg((i64)g.P1 * g.P0, g.N, paired), (i64)g.B * g.P1 * g.P0, g.N, g.rowstat >= 0);
+        // plain linear layers that keep the 128x128 tile (i.e. enough rows to fill the chip a few times over) run on the
+        // 256x128 / four-wave kernel (igemm_lin256.hip; same conditions as its lin256_ok). DMX_LIN256=0 switches it off (A/B).
+        {
+            const char *e = getenv("DMX_LIN256");
+            const bool on = !e || atoi(e) != 0;
+            const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.rowstat < 0 && g.S1 == 1 && g.pad0 == 0 &&
+                             g.seg0 == g.K && g.K == g.Kp && g.K % 16 == 0 && g.N % 4 == 0 &&
+                             (i64)(g.P0 - 1) * g.stride0 * g.Cin + g.seg0 <= (i64)g.L0 * g.Cin && g.P1 == g.L1 && g.stride1 == 1 && g.pad1 == 0 &&
+                             (g.epi != EPI_SCALE_RES || (g.res >= 0 && g.scale_w >= 0));
+            if (on && lin && g.cfg == 0 && g.N % 128 == 0)
+                g.cfg = 19;
+        }
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
         // (the direct kernels carry no residual operand for the LINEAR / TRCONV epilogues)
         const bool resOk = !((g.epi == EPI_LINEAR || g.epi == EPI_TRCONV) && g.res >= 0);

@@ -20,6 +20,8 @@ def kernel_class(name: str) -> str:
     if m:
         wm, wn, mf, nf = (int(x) for x in m.groups())
         return f"igemm_split_{wm * mf * 16}x{wn * nf * 16}"
+    if "igemm_lin256_kernel" in name:
+        return "igemm_lin256x128"
     for key, cls in (("lstm_kernel", "lstm"), ("local_attn_kernel", "local_attn"), ("group_stats", "group_stats"), ("gn_act_kernel", "gn_act"),
                      ("dgemm_k1_ring_kernel", "dgemm_k1_ring"), ("dgemm_kernel", "dgemm_direct"), ("attention_kernel", "attention"), ("track_stats", "track_stats"),
                      ("track_gather", "track_gather"), ("track_ola", "track_ola"), ("istft_ola", "istft_ola"), ("istft", "istft"), ("stft", "stft"),
