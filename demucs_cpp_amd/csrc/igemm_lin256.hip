@@ -30,13 +30,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float l2_gelu(float v) { return dmx_gelu(v); }
 
-template <int EPI>
+// STAT: the op also writes per-row (sum, sum of squares) partials of its 128-column block (plan.h rowstat), summed in the
+// order of igemm.hip: per lane over its 4 fragments, across the 4 lanes of a row (xor 16, 32), then wave 0 + wave 1.
+template <int EPI, bool STAT>
 __global__ __launch_bounds__(256, 2) void igemm_lin256_kernel(const GemmArgs p)
 {
     constexpr int BM = 256, BN = 128, WMF = 8, WNF = 4;
     __shared__ f32x4 As0[BM][4], As1[BM][4];
     __shared__ f32x4 Bs0[BN][4], Bs1[BN][4];
     __shared__ i64 rowBase[BM]; // element offset of a row's K-run in X, -1: row >= M
+    __shared__ float2 rsum[STAT ? BM : 1][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -233,8 +236,10 @@ __global__ __launch_bounds__(256, 2) void igemm_lin256_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
     {
-        const i64 m = m0 + wm * 128 + i * 16 + l15;
+        const int rl = wm * 128 + i * 16 + l15;
+        const i64 m = m0 + rl;
         const bool rowOk = m < p.M;
+        float rs = 0.f, rss = 0.f;
         f32x4 resv[WNF];
 #pragma unroll
         for (int j = 0; j < WNF; ++j)
@@ -260,15 +265,46 @@ __global__ __launch_bounds__(256, 2) void igemm_lin256_kernel(const GemmArgs p)
                 else
                     v = resv[j] + v * scalev[j];
                 *reinterpret_cast<f32x4 *>(p.Y + m * p.ldy + n) = v;
+                if (STAT)
+                {
+                    rs += (v[0] + v[1]) + (v[2] + v[3]);
+                    rss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+        }
+        if (STAT)
+        {
+            rs += __shfl_xor(rs, 16);
+            rss += __shfl_xor(rss, 16);
+            rs += __shfl_xor(rs, 32);
+            rss += __shfl_xor(rss, 32);
+            if (kq == 0)
+            {
+                rsum[rl][wn].x = rs;
+                rsum[rl][wn].y = rss;
+            }
+        }
+    }
+    if (STAT)
+    {
+        __syncthreads();
+        for (int r = tid; r < BM; r += 256)
+        {
+            const i64 m = m0 + r;
+            if (m < p.M)
+            {
+                float *dst = p.rowstat + (m * p.NB + tileN) * 2;
+                dst[0] = rsum[r][0].x + rsum[r][1].x;
+                dst[1] = rsum[r][0].y + rsum[r][1].y;
             }
         }
     }
 }
 
-// shapes this kernel covers: "linear layer" addressing (igemm.hip is_linear), no prologue, no row statistics
+// shapes this kernel covers: "linear layer" addressing (igemm.hip is_linear), no prologue
 bool lin256_ok(const GemmArgs &a)
 {
-    return a.pro == PRO_NONE && (a.epi == EPI_LINEAR || a.epi == EPI_SCALE_RES) && !a.rowstat && a.S1 == 1 && a.pad0 == 0 && a.seg0 == a.K &&
+    return a.pro == PRO_NONE && (a.epi == EPI_LINEAR || a.epi == EPI_SCALE_RES) && a.S1 == 1 && a.pad0 == 0 && a.seg0 == a.K &&
            a.K == a.Kp && a.K % 16 == 0 && a.Np % 4 == 0 && a.N % 4 == 0 && (i64)(a.P0 - 1) * a.stride0 * a.Cin + a.seg0 <= (i64)a.L0 * a.Cin &&
            a.P1 == a.L1 && a.stride1 == 1 && a.pad1 == 0 && a.M < (1ll << 31) - 256 && (a.epi != EPI_SCALE_RES || (a.res && a.scale));
 }
@@ -285,10 +321,14 @@ int launch_igemm_lin256(const GemmArgs &a0, hipStream_t s, bool dry)
     a.xcdMap = 1;
     a.dP0 = make_fastdiv((unsigned)a.P0), a.dP1 = make_fastdiv((unsigned)a.P1);
     const unsigned blocks = 8u * ((a.tilesM + 7u) / 8u) * a.tilesN;
-    if (a.epi == EPI_LINEAR)
-        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_LINEAR>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.epi == EPI_LINEAR && !a.rowstat)
+        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_LINEAR, false>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.epi == EPI_LINEAR)
+        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_LINEAR, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (!a.rowstat)
+        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_SCALE_RES, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_SCALE_RES>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((igemm_lin256_kernel<EPI_SCALE_RES, true>), dim3(blocks), dim3(256), 0, s, a);
     return 0;
 }
 

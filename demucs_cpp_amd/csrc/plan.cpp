@@ -206,11 +206,17 @@ struct Builder
         {
             const char *e = getenv("DMX_LIN256");
             const bool on = !e || atoi(e) != 0;
-            const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.rowstat < 0 && g.S1 == 1 && g.pad0 == 0 &&
+            const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.S1 == 1 && g.pad0 == 0 &&
                              g.seg0 == g.K && g.K == g.Kp && g.K % 16 == 0 && g.N % 4 == 0 &&
                              (i64)(g.P0 - 1) * g.stride0 * g.Cin + g.seg0 <= (i64)g.L0 * g.Cin && g.P1 == g.L1 && g.stride1 == 1 && g.pad1 == 0 &&
                              (g.epi != EPI_SCALE_RES || (g.res >= 0 && g.scale_w >= 0));
-            if (on && lin && g.cfg == 0 && g.N % 128 == 0)
+            // N a multiple of 512 only: with three column tiles (N = 384: the channel up / down samplers) half as many, twice as
+            // large workgroups quantise worse on the 64 slots of an XCD than they gain (measured 126 -> 115, 121 -> 111 TFLOP/s)
+            // ... and at least three rounds of its workgroups on the 64 slots of an XCD (the tile map deals row tiles to XCDs): at
+            // 1.75 rounds (time-branch linears with N = 512 at 42 segments) the 128x128 tile is 10 % faster
+            const i64 M = (i64)g.B * g.P1 * g.P0;
+            const i64 perXcd = (((M + 255) / 256 + 7) / 8) * ((g.N + 127) / 128);
+            if (on && lin && g.cfg == 0 && g.N % 512 == 0 && perXcd >= 192)
                 g.cfg = 19;
         }
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table

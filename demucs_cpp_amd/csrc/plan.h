@@ -312,7 +312,7 @@ static const TileCfg kTileCfgs[] = {
     {32, 64},   // 16  of 9
     {256, 128}, // 17  double-height sibling of 0 (8 waves, one workgroup per CU); experiment behind DMX_TALL=1
     {256, 128}, // 18  the same tile with FOUR waves of 128x64 and 16-deep K-tiles (two workgroups per CU); experiment, DMX_TALL=2
-    {256, 128}, // 19  igemm_lin256.hip: that tile with its own pipelined loop, linear layers without row statistics only
+    {256, 128}, // 19  igemm_lin256.hip: that tile with its own pipelined loop, linear layers only
                 //     (same column decomposition as 0 / 7, bit-identical results)
 };
 static const int kNumTileCfgs = 20;

@@ -42,7 +42,7 @@ for PB in (42, 12):
     for n in a:
         if b[n][1] == "igemm_lin256x128":
             ta += a[n][2]; tb += b[n][2]
-            key = n.split(".")[-1] if "crosstransformer" in n else n
+            key = (n.split(".")[-1] + ("_t" if "layers_t" in n else "")) if "crosstransformer" in n else n
             if key in seen: continue
             seen.add(key)
             f = lambda r: r[3] / r[2] / 1e9
