@@ -6,6 +6,7 @@
 // src/layers.cpp:377-531, STFT/ISTFT src/dsp.cpp:51-185. Fusions relative to the
 // reference are documented per op in DESIGN.md §4.
 #include "plan.h"
+#include <string>
 
 #include <algorithm>
 #include <cassert>
@@ -204,8 +205,9 @@ struct Builder
         // plain linear layers that keep the 128x128 tile (i.e. enough rows to fill the chip a few times over) run on the
         // 256x128 / four-wave kernel (igemm_lin256.hip; same conditions as its lin256_ok). DMX_LIN256=0 switches it off (A/B).
         {
-            const char *e = getenv("DMX_LIN256");
-            const bool on = !e || atoi(e) != 0;
+            const char *e = getenv("DMX_LIN256"), *ge = getenv("DMX_GEMM");
+            // (the operand-split experiment has no 256x128 form: its linears stay on the tiles igemm_split.hip instantiates)
+            const bool on = (!e || atoi(e) != 0) && !(ge && std::string(ge) == "bf16x3");
             const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.S1 == 1 && g.pad0 == 0 &&
                              g.seg0 == g.K && g.K == g.Kp && g.K % 16 == 0 && g.N % 4 == 0 &&
                              (i64)(g.P0 - 1) * g.stride0 * g.Cin + g.seg0 <= (i64)g.L0 * g.Cin && g.P1 == g.L1 && g.stride1 == 1 && g.pad1 == 0 &&

@@ -815,6 +815,37 @@ def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp
     m.close()
 
 
+def test_lin256_kernel_equals_the_128x128_tile_bitwise(dmx, tmp_models, monkeypatch):
+    """The transformer linears on the 256x128 / four-wave kernel (csrc/igemm_lin256.hip) against the 128x128
+    tile of igemm.hip they replace at large batches (DMX_LIN256=0): same k-ordered fmaf chain per element and the same
+    summation order of the row statistics, so every output bit must agree. 38 segments: enough rows for all its
+    variants (LINEAR, LINEAR + GELU, SCALE_RES + row statistics) to be selected; the plan dump confirms they are."""
+    import torch
+    m = dmx.Model(tmp_models[4])
+    B = 38
+    mix = (0.1 * np.random.default_rng(91).standard_normal((B, SEG_FULL, 2))).astype(np.float32)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DMX_LIN256", mode)
+        ctx = dmx.Context(m, 0, B)
+        d_mix = torch.from_numpy(mix).cuda()
+        d_out = torch.zeros((B, 4, 2, SEG_FULL), device="cuda", dtype=torch.float32)
+        ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+        ctx.synchronize()
+        classes = {r[0]: r[1] for r in ctx.profile(B, 1)}
+        on_new = [n for n, k in classes.items() if k == "igemm_lin256x128"]
+        if mode == "1":
+            assert any(n.endswith(".qkv") for n in on_new) and any(n.endswith(".linear1") for n in on_new) and \
+                any(n.endswith(".linear2") for n in on_new), on_new
+        else:
+            assert not on_new
+        outs.append(d_out.cpu().numpy())
+        ctx.close()
+        del d_out, d_mix
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    m.close()
+
+
 def test_run_to_run_determinism_stress():
     """tools/stress_determinism.py at 12 repeats: the same batch (24, 4, 1 segments; 6-source model at 12) through the
     hot path again and again, every output bit-identical to the first. (This is the test that caught a missing
