@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_
 // small pieces BETWEEN the eight 16-MFMA groups of tile t (pinned with sched_barrier), so a wave's
 // instruction stream is a uniform MFMA-dominated mix with no long matrix-idle stretch.
 template <int WAVES_M, int WAVES_N, int WMF, int WNF, int KS, int PRO, int EPI, bool LIN, bool IL>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF == 8 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 ? 2 : DMX_KS1_WAVES) void igemm_kernel(const GemmArgs p)
 {
     static_assert(!IL || KS == 2, "interleaved loop is written for 2 k-chunks per tile");
     constexpr int NT = WAVES_M * WAVES_N * 64; // 256 threads; 512 for the double-height tile (4 x 2 waves, ONE workgroup per CU)
@@ -1025,6 +1025,10 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_GLU)
         DMX_CASE(18, 2, 2, 8, 4, 1, PRO_NONE, EPI_TRCONV)
+        // cfg 20: 256x96 with four waves of 64x96 and 16-deep K-tiles, plain loop: the short-K ops of the 128x96 family
+        DMX_CASE(20, 4, 1, 4, 6, 1, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(20, 4, 1, 4, 6, 1, PRO_NONE, EPI_GLU)
+        DMX_CASE(20, 4, 1, 4, 6, 1, PRO_NONE, EPI_TRCONV)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_LINEAR)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, DMX_BIG_KS, PRO_NONE, EPI_GLU)

@@ -109,6 +109,8 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
         return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
+    if (cfg == 2 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 3 && M >= 256 * 256)
+        return 20;
     if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 2 && M >= 256 * 256)
         return 18;
     if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 1 && M >= 256 * 256)
@@ -220,6 +222,15 @@ struct Builder
             const i64 perXcd = (((M + 255) / 256 + 7) / 8) * ((g.N + 127) / 128);
             if (on && lin && g.cfg == 0 && g.N % 512 == 0 && perXcd >= 192)
                 g.cfg = 19;
+            // short-K ops of the 128x96 family (K <= 160: the level-1 1x1 rewrites, K = 96, and the time branch's last k3
+            // rewrite, K = 144) run on the 256x96 tile with 16-deep K-tiles (cfg 20, plain loop): no half-empty last K-tile
+            // (144 = 4.5 x 32) and a shorter pipeline fill - measured 88.8 -> 101.9, 84.6 -> 93.9, 90.4 -> 94.8 TFLOP/s at 42
+            // segments; longer K stays on the interleaved 32-deep loop (decoder.3.rewrite, K = 432: 121 vs 118.7). Same column
+            // decomposition and k order: identical bits. DMX_SHORTK=0 switches it off (A/B).
+            const char *sk = getenv("DMX_SHORTK");
+            if ((!sk || atoi(sk) != 0) && g.cfg == 2 && g.rowstat < 0 && g.pro == PRO_NONE &&
+                (g.epi == EPI_LINEAR || g.epi == EPI_GLU || g.epi == EPI_TRCONV) && g.K <= 160 && M >= 65536)
+                g.cfg = 20;
         }
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
         // (the direct kernels carry no residual operand for the LINEAR / TRCONV epilogues)

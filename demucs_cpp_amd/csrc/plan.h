@@ -314,8 +314,10 @@ static const TileCfg kTileCfgs[] = {
     {256, 128}, // 18  the same tile with FOUR waves of 128x64 and 16-deep K-tiles (two workgroups per CU); experiment, DMX_TALL=2
     {256, 128}, // 19  igemm_lin256.hip: that tile with its own pipelined loop, linear layers only
                 //     (same column decomposition as 0 / 7, bit-identical results)
+    {256, 96},  // 20  four waves of 64x96, 16-deep K-tiles, plain loop: the short-K ops of the 128x96 family (plan.cpp); all of
+                //     that family with DMX_TALL=3 (probe)
 };
-static const int kNumTileCfgs = 20;
+static const int kNumTileCfgs = 21;
 static const int kDirectCfg = 8;
 // cfg -> its half-height sibling (-1: none); stat = the op writes row statistics
 int half_cfg(int cfg, bool stat);

@@ -139,10 +139,10 @@ def test_two_stream_waits_cover_every_hazard(ns, interp, tmp_models):
 
 TILES = {0: (128, 128), 1: (64, 64), 2: (128, 96), 3: (128, 48), 4: (256, 16), 5: (128, 32), 6: (128, 64), 7: (64, 128), 8: (16, 256),
          9: (64, 64), 10: (64, 96), 11: (64, 48), 12: (64, 32), 13: (64, 64), 14: (128, 16), 15: (32, 128), 16: (32, 64),
-         17: (256, 128), 18: (256, 128), 19: (256, 128)}  # 17 / 18: experiment tiles (DMX_TALL); 19: igemm_lin256.hip, linear layers
+         17: (256, 128), 18: (256, 128), 19: (256, 128), 20: (256, 96)}  # 17 / 18: experiment tiles (DMX_TALL); 19: igemm_lin256.hip, linear layers
 # cfg -> family (column decomposition: waves x fragments along N); siblings of a family give identical bits,
 # the families with row statistics never cross (plan.h)
-FAMILY = {0: "2x4", 7: "2x4", 15: "2x4", 17: "2x4", 18: "2x4", 19: "2x4", 9: "2x2", 16: "2x2", 2: "1x6", 10: "1x6", 3: "1x3", 11: "1x3", 5: "1x2", 12: "1x2",
+FAMILY = {0: "2x4", 7: "2x4", 15: "2x4", 17: "2x4", 18: "2x4", 19: "2x4", 20: "1x6", 9: "2x2", 16: "2x2", 2: "1x6", 10: "1x6", 3: "1x3", 11: "1x3", 5: "1x2", 12: "1x2",
           6: "1x4", 13: "1x4", 4: "1x1", 14: "1x1", 8: "direct", 1: "2x2o"}
 
 
