@@ -846,6 +846,32 @@ def test_lin256_kernel_equals_the_128x128_tile_bitwise(dmx, tmp_models, monkeypa
     m.close()
 
 
+@pytest.mark.parametrize("which", [4, 3])
+def test_short_k_tile_equals_the_128x96_tile_bitwise(which, dmx, tmp_models, monkeypatch):
+    """Short-K ops of the 128x96 tile family (K <= 160: the level-1 1x1 rewrites, the time branch's last k3 rewrite) run on
+    a 256x96 tile with 16-deep K-tiles at large batches (plan.cpp); DMX_SHORTK=0 keeps them on the 128x96
+    tile. Same column decomposition and k order: identical bits (htdemucs-4s and hdemucs_mmi)."""
+    import torch
+    m = dmx.Model(tmp_models[which])
+    B = 26
+    mix = (0.1 * np.random.default_rng(92).standard_normal((B, SEG_FULL, 2))).astype(np.float32)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DMX_SHORTK", mode)
+        ctx = dmx.Context(m, 0, B)
+        d_mix = torch.from_numpy(mix).cuda()
+        d_out = torch.zeros((B, 4, 2, SEG_FULL), device="cuda", dtype=torch.float32)
+        ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+        ctx.synchronize()
+        on_new = [r[0] for r in ctx.profile(B, 1) if r[1] == "igemm_256x96w4"]
+        assert (len(on_new) >= 3) if mode == "1" else not on_new, on_new
+        outs.append(d_out.cpu().numpy())
+        ctx.close()
+        del d_out, d_mix
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    m.close()
+
+
 def test_run_to_run_determinism_stress():
     """tools/stress_determinism.py at 12 repeats: the same batch (24, 4, 1 segments; 6-source model at 12) through the
     hot path again and again, every output bit-identical to the first. (This is the test that caught a missing
