@@ -228,7 +228,8 @@ struct Builder
             // segments; longer K stays on the interleaved 32-deep loop (decoder.3.rewrite, K = 432: 121 vs 118.7). Same column
             // decomposition and k order: identical bits. DMX_SHORTK=0 switches it off (A/B).
             const char *sk = getenv("DMX_SHORTK");
-            if ((!sk || atoi(sk) != 0) && g.cfg == 2 && g.rowstat < 0 && g.pro == PRO_NONE &&
+            const bool splitExp = ge && std::string(ge) == "bf16x3"; // the operand-split experiment keeps the tiles it instantiates
+            if ((!sk || atoi(sk) != 0) && !splitExp && g.cfg == 2 && g.rowstat < 0 && g.pro == PRO_NONE &&
                 (g.epi == EPI_LINEAR || g.epi == EPI_GLU || g.epi == EPI_TRCONV) && g.K <= 160 && M >= 65536)
                 g.cfg = 20;
         }
