@@ -958,7 +958,7 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
 {
     static const char *cfgNames[] = {"igemm_128x128", "igemm_64x64", "igemm_128x96", "igemm_128x48", "igemm_256x16", "igemm_128x32",
                                      "igemm_128x64",  "igemm_64x128", "dgemm_direct", "igemm_64x64", "igemm_64x96", "igemm_64x48",
-                                     "igemm_64x32",   "igemm_64x64",  "igemm_128x16", "igemm_32x128", "igemm_32x64", "igemm_256x128", "igemm_256x128w4", "igemm_lin256x128", "igemm_256x96w4"};
+                                     "igemm_64x32",   "igemm_64x64",  "igemm_128x16", "igemm_32x128", "igemm_32x64", "igemm_256x128", "igemm_256x128w4", "igemm_lin256x128", "igemm_256x96"};
     static_assert(sizeof(cfgNames) / sizeof(cfgNames[0]) == kNumTileCfgs, "one label per tile configuration");
     flops = bytes = 0;
     kernel = "?";

@@ -863,7 +863,7 @@ def test_short_k_tile_equals_the_128x96_tile_bitwise(which, dmx, tmp_models, mon
         d_out = torch.zeros((B, 4, 2, SEG_FULL), device="cuda", dtype=torch.float32)
         ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
         ctx.synchronize()
-        on_new = [r[0] for r in ctx.profile(B, 1) if r[1] == "igemm_256x96w4"]
+        on_new = [r[0] for r in ctx.profile(B, 1) if r[1] == "igemm_256x96"]
         assert (len(on_new) >= 3) if mode == "1" else not on_new, on_new
         outs.append(d_out.cpu().numpy())
         ctx.close()

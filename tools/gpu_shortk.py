@@ -15,7 +15,7 @@ for ns, arch in ((4, "v4"), (6, "v4"), (4, "v3")):
         d_mix = torch.from_numpy(mix).cuda(); d_out = torch.zeros(PB, ns, 2, 343980, device='cuda')
         ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), PB); ctx.synchronize()
         outs[on] = d_out.cpu().numpy()
-        if ns == 4: print(arch, "DMX_SHORTK", on, "sum of ops", round(sum(r[2] for r in ctx.profile(PB, 3)), 3), [r[0] for r in ctx.profile(PB,1) if r[1]=="igemm_256x96w4"])
+        if ns == 4: print(arch, "DMX_SHORTK", on, "sum of ops", round(sum(r[2] for r in ctx.profile(PB, 3)), 3), [r[0] for r in ctx.profile(PB,1) if r[1]=="igemm_256x96"])
         ctx.close()
     print(f"{arch} {ns}s batch {PB}: short-K tile == 128x96 bitwise:", np.array_equal(outs["0"], outs["1"]), bool(np.isfinite(outs["1"]).all()))
     m.close()

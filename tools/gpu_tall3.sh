@@ -12,7 +12,7 @@ def load(f): return {l.split("\t")[0]: l.rstrip("\n").split("\t") for l in open(
 p, w, k = load("gpurun_out/tall3_product.tsv"), load("gpurun_out/tall3_w4.tsv"), load("gpurun_out/tall3_ks1.tsv")
 tp = tw = tk = 0
 for n in p:
-    if w[n][1] == "igemm_256x96w4":
+    if w[n][1] == "igemm_256x96":
         f = lambda r: float(r[3]) / float(r[2]) / 1e9
         tp += float(p[n][2]); tw += float(w[n][2]); tk += float(k[n][2])
         print(f"{n:28s} product {p[n][1]:13s} {float(p[n][2])*1e3:7.0f} us {f(p[n]):6.1f} | plain 16-deep loop: 128x96 {f(k[n]):6.1f}  256x96/4 waves {f(w[n]):6.1f} TF/s")
