@@ -8,7 +8,7 @@ OBJS := $(addprefix build/,igemm.o igemm_split.o igemm_lin256.o dgemm.o fft.o mi
 
 all: $(LIB) cli oracle interp harness micro
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/plan.h $(CSRC)/api_internal.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/plan.h $(CSRC)/api_internal.h $(CSRC)/igemm_common.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 build/%.o: $(CSRC)/%.cpp $(CSRC)/kernels.h $(CSRC)/plan.h $(CSRC)/api_internal.h include/demucs_hip.h

@@ -21,7 +21,8 @@ int main(int argc, const char **argv)
     std::string model_dir = argv[1], wav_file = argv[2], out_dir = argv[3];
     StereoMatrix audio;
     int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
-    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
+    int64_t native_frames = -1;              // frames of the source file when it was converted
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate, &native_frames))
         exit(1);
     // One bag engine instead of four demucs_model objects: the (model, segment) items of all four models are
     // dealt over the devices of DMX_DEVICES together (csrc/engine.cpp); each model still draws its own shift
@@ -71,7 +72,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * k)] = t(i, 0, k);
             wave[(size_t)(2 * k + 1)] = t(i, 1, k);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate, native_frames))
             exit(1);
     }
     return 0;

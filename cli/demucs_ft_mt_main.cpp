@@ -32,7 +32,8 @@ int main(int argc, const char **argv)
     }
     StereoMatrix audio;
     int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
-    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
+    int64_t native_frames = -1;              // frames of the source file when it was converted
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate, &native_frames))
         exit(1);
     std::array<demucs_model, 4> models;
     static const char *keys[4] = {"htdemucs_ft_drums", "htdemucs_ft_bass", "htdemucs_ft_other", "htdemucs_ft_vocals"};
@@ -74,7 +75,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * k)] = t(i, 0, k);
             wave[(size_t)(2 * k + 1)] = t(i, 1, k);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate, native_frames))
             exit(1);
     }
     return 0;

@@ -33,7 +33,8 @@ int main(int argc, const char **argv)
     }
     StereoMatrix audio;
     int native_rate = SUPPORTED_SAMPLE_RATE; // != 44100 only with DMX_RESAMPLE=1 (wav.hpp)
-    if (!wavio::load_audio_file(wav_file, audio, &native_rate))
+    int64_t native_frames = -1;              // frames of the source file when it was converted
+    if (!wavio::load_audio_file(wav_file, audio, &native_rate, &native_frames))
         exit(1);
     demucs_model model;
     auto ret = load_demucs_model(model_file, &model);
@@ -59,7 +60,7 @@ int main(int argc, const char **argv)
             wave[(size_t)(2 * i)] = out(target, 0, i);
             wave[(size_t)(2 * i + 1)] = out(target, 1, i);
         }
-        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate))
+        if (!wavio::write_audio_file(wave.data(), audio.cols(), p_target.string(), native_rate, native_frames))
         {
             std::cerr << "Error writing " << p_target << std::endl;
             exit(1);

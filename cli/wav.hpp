@@ -21,13 +21,6 @@
 
 namespace wavio
 {
-// frames of the file a converted track came from: the stems are cut back to it on the way out (the round trip
-// ceil(ceil(N L/M) M/L) is up to a few samples longer than N, and a stem must line up with its source file)
-inline int64_t &native_frames()
-{
-    static int64_t n = -1;
-    return n;
-}
 inline int resample_device()
 {
     const char *d = getenv("DMX_DEVICE");
@@ -35,8 +28,12 @@ inline int resample_device()
 }
 
 // native_rate (optional): receives the file's sample rate; a rate other than 44.1 kHz is accepted only when the
-// caller passes it AND the environment says DMX_RESAMPLE=1
-inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix &out, int *native_rate = nullptr)
+// caller passes it AND the environment says DMX_RESAMPLE=1. native_frames (optional): receives the frame count of the
+// file when the track was converted (-1 otherwise): write_audio_file cuts the stems back to it (the round trip
+// ceil(ceil(N L/M) M/L) is up to a few samples longer than N, and a stem must line up with ITS source file - the count
+// travels with the caller, not in a process-wide variable, so several files may be in flight).
+inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix &out, int *native_rate = nullptr,
+                            int64_t *native_frames = nullptr)
 {
     FILE *f = fopen(filename.c_str(), "rb");
     if (!f)
@@ -103,6 +100,8 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
     }
     if (native_rate)
         *native_rate = (int)rate;
+    if (native_frames)
+        *native_frames = -1;
     if (nch != 1 && nch != 2)
     {
         std::cerr << "[ERROR] demucs.cpp only supports mono and stereo audio" << std::endl; // :42-48
@@ -188,14 +187,16 @@ inline bool load_audio_file(const std::string &filename, demucscpp::StereoMatrix
         }
         std::cout << "Converted " << rate << " Hz -> " << demucscpp::SUPPORTED_SAMPLE_RATE << " Hz on the GPU: " << n441 << " samples" << std::endl;
         out = std::move(conv);
-        native_frames() = (int64_t)N;
+        if (native_frames)
+            *native_frames = (int64_t)N;
     }
     return true;
 }
 
 // stereo float32 WAV; `interleaved` = 2*N floats at 44.1 kHz. out_rate != 44100 (a track that was converted on the way
-// in): the stem is converted to that rate on the GPU first.
-inline bool write_audio_file(const float *interleaved, int64_t N, const std::string &filename, int out_rate = 44100)
+// in): the stem is converted to that rate on the GPU first and cut to native_frames (>= 0: what load_audio_file reported).
+inline bool write_audio_file(const float *interleaved, int64_t N, const std::string &filename, int out_rate = 44100,
+                             int64_t native_frames = -1)
 {
     std::vector<float> conv;
     if (out_rate != demucscpp::SUPPORTED_SAMPLE_RATE)
@@ -210,7 +211,7 @@ inline bool write_audio_file(const float *interleaved, int64_t N, const std::str
             return false;
         }
         interleaved = conv.data();
-        N = native_frames() >= 0 ? std::min<int64_t>(n2, native_frames()) : n2; // sample-aligned with the source file
+        N = native_frames >= 0 ? std::min<int64_t>(n2, native_frames) : n2; // sample-aligned with the source file
     }
     FILE *f = fopen(filename.c_str(), "wb");
     if (!f)

@@ -31,10 +31,13 @@ EXPORTS = [
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
+    "dmx_ctx_create_gemm", "dmx_ctx_gemm", "dmx_default_gemm", "dmx_set_default_gemm", "dmx_debug_split_weights", "dmx_debug_split_activations",
     "dmx_model_arch", "dmx_engine_arch", "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2
+GEMM_F32, GEMM_BF16X3 = 0, 1
+GEMM_NAMES = {GEMM_F32: "f32", GEMM_BF16X3: "bf16x3"}
 FINISH_ROOT, FINISH_OWNER = 0, 1
 
 _lib = None
@@ -69,6 +72,12 @@ def lib():
         for f in ("dmx_model_n_sources", "dmx_model_n_tensors", "dmx_model_device", "dmx_model_arch"):
             getattr(L, f).argtypes = [vp]
         L.dmx_ctx_create.argtypes = [vp, i64, ci, ctypes.POINTER(vp)]
+        L.dmx_ctx_create_gemm.argtypes = [vp, i64, ci, ci, ctypes.POINTER(vp)]
+        L.dmx_ctx_gemm.argtypes = [vp]
+        L.dmx_set_default_gemm.argtypes = [ci]
+        L.dmx_debug_split_weights.argtypes = [fp, i64, fp, fp]
+        L.dmx_debug_split_weights.restype = i64
+        L.dmx_debug_split_activations.argtypes = [ci, fp, i64, fp]
         L.dmx_ctx_free.argtypes = [vp]
         L.dmx_ctx_segment_samples.argtypes = [vp]
         L.dmx_ctx_segment_samples.restype = i64
@@ -133,11 +142,41 @@ class Model:
             pass
 
 
+def default_gemm() -> int:
+    return lib().dmx_default_gemm()
+
+
+def set_default_gemm(gemm: int):
+    """GEMM arithmetic of contexts (and engines) created from now on: GEMM_F32 | GEMM_BF16X3."""
+    _chk(lib().dmx_set_default_gemm(gemm))
+
+
+def split_weights(w: np.ndarray):
+    """(w1, w2, n_inexact): bf16 bit patterns of the two-term weight split of GEMM_BF16X3 (host function)."""
+    w = np.ascontiguousarray(w, np.float32).ravel()
+    w1 = np.zeros(w.size, np.uint16)
+    w2 = np.zeros(w.size, np.uint16)
+    bad = lib().dmx_debug_split_weights(w.ctypes.data, w.size, w1.ctypes.data, w2.ctypes.data)
+    return w1, w2, int(bad)
+
+
+def split_activations(x: np.ndarray, device: int = 0) -> np.ndarray:
+    """(3, n) bf16 bit patterns a1, a2, a3 of the kernels' three-term activation split (runs on the GPU)."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    planes = np.zeros((3, x.size), np.uint16)
+    _chk(lib().dmx_debug_split_activations(device, x.ctypes.data, x.size, planes.ctypes.data))
+    return planes
+
+
 class Context:
-    def __init__(self, model: Model, segment_samples: int = 0, max_batch: int = 1):
+    def __init__(self, model: Model, segment_samples: int = 0, max_batch: int = 1, gemm: Optional[int] = None):
         self.model = model
         self.h = ctypes.c_void_p()
-        _chk(lib().dmx_ctx_create(model.h, segment_samples, max_batch, ctypes.byref(self.h)))
+        if gemm is None:
+            _chk(lib().dmx_ctx_create(model.h, segment_samples, max_batch, ctypes.byref(self.h)))
+        else:
+            _chk(lib().dmx_ctx_create_gemm(model.h, segment_samples, max_batch, gemm, ctypes.byref(self.h)))
+        self.gemm = lib().dmx_ctx_gemm(self.h)
         self.seg = lib().dmx_ctx_segment_samples(self.h)
         self.max_batch = max_batch
         self.S = model.n_sources
@@ -159,6 +198,11 @@ class Context:
 
     def synchronize(self):
         _chk(lib().dmx_ctx_synchronize(self.h))
+
+    def set_model(self, model: "Model"):
+        """Rebind to another model of the same architecture on the same device (the fine-tuned bag shares one arena)."""
+        _chk(lib().dmx_ctx_set_model(self.h, model.h))
+        self.model = model
 
     def set_stream(self, hip_stream: Optional[int]):
         """Order the context's device work on a caller-owned hipStream_t (raw handle, e.g.

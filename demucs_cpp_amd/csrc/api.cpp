@@ -7,11 +7,19 @@
 // No CPU fallback exists: without a usable HIP device every compute entry point fails.
 #include "api_internal.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <cctype>
+#include <cerrno>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace dmx;
 
@@ -65,20 +73,69 @@ extern "C" int dmx_model_load(const char *model_file, int device, dmx_model **ou
     return DMX_OK;
 }
 
-// EXPERIMENT switch: DMX_GEMM=bf16x3 routes the MFMA-bound igemm ops through the exact-split bf16 kernels
-bool split_gemm_enabled()
+// ---- GEMM arithmetic of a context (include/demucs_hip.h DMX_GEMM_*). The process default comes from the environment
+// (DMX_GEMM=f32|bf16x3) the first time it is needed and can be changed with dmx_set_default_gemm; a context keeps the
+// mode it was created with.
+static std::atomic<int> g_defaultGemm{-1};
+extern "C" int dmx_default_gemm(void)
 {
-    static const bool on = [] {
+    int g = g_defaultGemm.load();
+    if (g < 0)
+    {
         const char *e = getenv("DMX_GEMM");
-        return e && !strcmp(e, "bf16x3");
-    }();
-    return on;
+        g = e && !strcmp(e, "bf16x3") ? DMX_GEMM_BF16X3 : DMX_GEMM_F32;
+        g_defaultGemm.store(g);
+    }
+    return g;
 }
+extern "C" int dmx_set_default_gemm(int gemm)
+{
+    if (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3)
+        return fail(DMX_ERR_ARG, "dmx_set_default_gemm: unknown mode %d", gemm);
+    g_defaultGemm.store(gemm);
+    return DMX_OK;
+}
+// pure host function (tests): the two-term weight split of the exact-split GEMM path; returns the number of inexact elements
+extern "C" int64_t dmx_debug_split_weights(const float *w, int64_t n, unsigned short *w1, unsigned short *w2)
+{
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i)
+        bad += dmx_split_weight(w[i], w1[i], w2[i]) ? 0 : 1;
+    return bad;
+}
+
+extern "C" int dmx_debug_split_activations(int device, const float *x, int64_t n, unsigned short *planes)
+{
+    if (!x || !planes || n < 1)
+        return fail(DMX_ERR_ARG, "dmx_debug_split_activations: invalid argument");
+    if (device < 0 || device >= dmx_device_count())
+        return fail(DMX_ERR_NO_DEVICE, "dmx_debug_split_activations: no such HIP device (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    float *dx = nullptr;
+    unsigned short *dp = nullptr;
+    HIPCHK(hipMalloc((void **)&dx, sizeof(float) * (size_t)n));
+    hipError_t e = hipMalloc((void **)&dp, sizeof(unsigned short) * 3 * (size_t)n);
+    if (e == hipSuccess)
+        e = hipMemcpy(dx, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        launch_split3_debug(dx, n, dp, nullptr);
+        e = hipMemcpy(planes, dp, sizeof(unsigned short) * 3 * (size_t)n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dx);
+    if (dp)
+        (void)hipFree(dp);
+    if (e != hipSuccess)
+        return fail(DMX_ERR_HIP, "dmx_debug_split_activations: %s", hipGetErrorString(e));
+    return DMX_OK;
+}
+
 // an op may use the split kernel when a kernel exists for its (tile, prologue, epilogue) and every weight it reads is the
 // exact sum of its two bf16 planes (true for tensors that come straight from the fp16 file; derived ones keep fp32)
-static bool split_ok(const dmx_model *m, const IGemm &g)
+static bool split_ok(const dmx_ctx *c, const IGemm &g)
 {
-    if (!split_gemm_enabled() || !m->dWb || m->pm.blob.size() != m->blobFloats)
+    const dmx_model *m = c->m;
+    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb || m->pm.blob.size() != m->blobFloats)
         return false;
     GemmArgs k{};
     k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
@@ -88,17 +145,8 @@ static bool split_ok(const dmx_model *m, const IGemm &g)
     const float *w = m->pm.blob.data() + g.w_w;
     for (i64 i = 0; i < (i64)g.Np * g.Kp; ++i)
     {
-        unsigned u;
-        std::memcpy(&u, &w[i], 4);
-        const unsigned h1 = u & 0xffff0000u;
-        float f1, f2;
-        std::memcpy(&f1, &h1, 4);
-        const float r = w[i] - f1;
-        unsigned ur;
-        std::memcpy(&ur, &r, 4);
-        ur &= 0xffff0000u;
-        std::memcpy(&f2, &ur, 4);
-        if (f1 + f2 != w[i])
+        unsigned short w1, w2;
+        if (!dmx_split_weight(w[i], w1, w2))
             return false;
     }
     return true;
@@ -119,25 +167,13 @@ int dmx_model_upload(dmx_model *m, const float *blob)
         m->dW = nullptr;
         return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
     }
-    if (split_gemm_enabled())
     {
-        // EXPERIMENT (igemm_split.hip): every blob element as two bf16 terms by truncation, w1 = top 16 bits of w,
-        // w2 = top 16 bits of (w - w1). Exact for fp16-representable values (11 significand bits); whether an op's weights
-        // ARE exact is checked per op when the plan is built (split_ok).
+        // igemm_split.hip: every blob element as two bf16 terms by round-to-nearest splits, w1 = bf16(w), w2 = bf16(w - w1).
+        // Exact for fp16-representable values (11 significand bits <= 8 + 8, fp16 subnormals included: bf16 has the fp32
+        // exponent range); whether an op's weights ARE exact is checked per op when the plan is built (split_ok).
         std::vector<unsigned short> planes(2 * m->blobFloats + 1024, 0);
         for (size_t i = 0; i < m->blobFloats; ++i)
-        {
-            unsigned u;
-            std::memcpy(&u, &blob[i], 4);
-            const unsigned h1 = u & 0xffff0000u;
-            float f1, r;
-            std::memcpy(&f1, &h1, 4);
-            r = blob[i] - f1;
-            unsigned ur;
-            std::memcpy(&ur, &r, 4);
-            planes[i] = (unsigned short)(h1 >> 16);
-            planes[m->blobFloats + 512 + i] = (unsigned short)(ur >> 16);
-        }
+            (void)dmx_split_weight(blob[i], planes[i], planes[m->blobFloats + 512 + i]);
         HIPCHK(hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short)));
         HIPCHK(hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
@@ -212,18 +248,21 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     if (it != c->plans.end())
         return it->second.get();
     auto p = std::make_unique<Plan>();
-    build_plan(c->m->pm, c->seg, batch, *p);
+    PlanOpts opts;
+    opts.gemm = c->gemm;
+    build_plan(c->m->pm, c->seg, batch, *p, opts);
     for (Op &op : p->ops)
         if (op.kind == OP_IGEMM)
-            op.g.split = split_ok(c->m, op.g) ? 1 : 0;
+            op.g.split = split_ok(c, op.g) ? 1 : 0;
     Plan *raw = p.get();
     c->plans[batch] = std::move(p);
     return raw;
 }
 
-static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int max_batch)
+static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int max_batch, int gemm)
 {
     c->m = m;
+    c->gemm = gemm;
     c->seg = segment_samples;
     c->maxBatch = max_batch;
     HIPCHK(hipSetDevice(m->device));
@@ -254,12 +293,21 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     HIPCHK(hipMalloc((void **)&c->dStats, sizeof(float) * 4));
     HIPCHK(hipMalloc((void **)&c->dStatus, sizeof(unsigned)));
     HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&c->hStatus, sizeof(unsigned), hipHostMallocDefault));
+    *c->hStatus = 0;
     return DMX_OK;
 }
 
 extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out)
 {
-    if (!m || !out || max_batch < 1 || max_batch > 64)
+    return dmx_ctx_create_gemm(m, segment_samples, max_batch, dmx_default_gemm(), out);
+}
+
+extern "C" int dmx_ctx_gemm(const dmx_ctx *c) { return c ? c->gemm : -1; }
+
+extern "C" int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, int max_batch, int gemm, dmx_ctx **out)
+{
+    if (!m || !out || max_batch < 1 || max_batch > 64 || (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3))
         return fail(DMX_ERR_ARG, "dmx_ctx_create: invalid argument");
     *out = nullptr;
     if (segment_samples == 0)
@@ -267,7 +315,7 @@ extern "C" int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int m
     if (segment_samples < 4096 || segment_samples % 2 != 0)
         return fail(DMX_ERR_ARG, "dmx_ctx_create: segment_samples must be even and >= 4096");
     auto c = std::make_unique<dmx_ctx>(); // ~dmx_ctx releases whatever an early return leaves behind
-    DMXCHK(ctx_init(c.get(), m, segment_samples, max_batch));
+    DMXCHK(ctx_init(c.get(), m, segment_samples, max_batch, gemm));
     *out = c.release();
     return DMX_OK;
 }
@@ -310,6 +358,8 @@ dmx_ctx::~dmx_ctx()
                     (void *)bSegOut.p, (void *)bOut.p})
         if (p)
             (void)hipFree(p);
+    if (hStatus)
+        (void)hipHostFree(hStatus);
 }
 
 extern "C" void dmx_ctx_free(dmx_ctx *c) { delete c; }
@@ -353,24 +403,31 @@ hipEvent_t dmx_batch_event(dmx_ctx *c, size_t i)
 extern "C" int64_t dmx_ctx_segment_samples(const dmx_ctx *c) { return c ? c->seg : 0; }
 extern "C" int dmx_ctx_max_batch(const dmx_ctx *c) { return c ? c->maxBatch : 0; }
 extern "C" int64_t dmx_ctx_arena_bytes(const dmx_ctx *c) { return c ? c->arenaFloats * 4 : 0; }
+int dmx_ctx_sync_checked(dmx_ctx *c)
+{
+    // the cooperative LSTM kernel (Demucs v3) bounds its spins and raises the status word instead of hanging (v3.hip):
+    // its copy rides on the stream behind the work it reports on, into pinned memory - no second round trip, no
+    // legacy-stream synchronisation with other contexts' streams
+    const bool check = c->m->pm.arch == 3;
+    if (check)
+        HIPCHK(hipMemcpyAsync(c->hStatus, c->dStatus, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (check && *c->hStatus != 0)
+    {
+        *c->hStatus = 0;
+        HIPCHK(hipMemsetAsync(c->dStatus, 0, sizeof(unsigned), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return fail(DMX_ERR_HIP, "a cooperative kernel timed out waiting for its partner workgroups (results invalid)");
+    }
+    return DMX_OK;
+}
+
 extern "C" int dmx_ctx_synchronize(dmx_ctx *c)
 {
     if (!c)
         return fail(DMX_ERR_ARG, "null ctx");
     HIPCHK(hipSetDevice(c->m->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->m->pm.arch == 3)
-    {
-        // the cooperative LSTM kernel bounds its spins and raises this word instead of hanging (v3.hip)
-        unsigned st = 0;
-        HIPCHK(hipMemcpy(&st, c->dStatus, sizeof(st), hipMemcpyDeviceToHost));
-        if (st != 0)
-        {
-            HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
-            return fail(DMX_ERR_HIP, "dmx_ctx_synchronize: a cooperative kernel timed out waiting for its partner workgroups (results invalid)");
-        }
-    }
-    return DMX_OK;
+    return dmx_ctx_sync_checked(c);
 }
 
 extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
@@ -383,6 +440,144 @@ extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     return DMX_OK;
 }
+
+// --------------------------------------------------------------------------- LSTM lane
+// The cooperative LSTM kernel (v3.hip) spins on partner workgroups. Within ONE launch in-order dispatch makes that safe; a
+// launch is dealt to the XCDs in blocks of 8 recurrences (8 x 12 / 24 workgroups), so the unit that must be resident
+// together is 96 / 192 workgroups and three concurrent launches at H = 384 can exceed the 512 resident workgroups of the
+// device (the bounded spin then raises the status word: an error, never a hang). Launches on one device therefore form a
+// lane: each waits for the previous one's completion event, whatever stream or context of this process issued it. Graph
+// captures (batches below 8: at most 48 spinning workgroups per launch, i.e. ten concurrently replaying contexts fit)
+// stay outside, a capture cannot wait on a foreign event. Lanes are created on demand, one per visible device, and live
+// until the process ends (their events are not destroyed from a static destructor: the HIP runtime may be gone by then).
+struct SharedLane // one per GPU in POSIX shared memory, keyed by the PCI bus id
+{
+    std::atomic<int> ready;
+    std::atomic<int> nprocs;
+    pthread_mutex_t mu;
+};
+struct LstmLane
+{
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    bool recorded = false;
+    SharedLane *shared = nullptr;
+};
+static std::mutex g_lanesMu;
+static std::vector<std::unique_ptr<LstmLane>> g_lanes;
+static std::vector<SharedLane *> g_sharedRegistered;
+
+static SharedLane *open_shared_lane(int device)
+{
+    if (const char *e = getenv("DMX_LSTM_SHARED_LANE"))
+        if (atoi(e) == 0)
+            return nullptr;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess)
+        return nullptr;
+    std::string name = "/dmx_lstm_lane_";
+    for (const char *q = bus; *q; ++q)
+        name += (isalnum((unsigned char)*q) ? *q : '_');
+    bool creator = true;
+    int fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0666);
+    if (fd < 0)
+    {
+        creator = false;
+        fd = shm_open(name.c_str(), O_RDWR, 0666);
+    }
+    if (fd < 0)
+        return nullptr;
+    if (creator && ftruncate(fd, sizeof(SharedLane)) != 0)
+    {
+        close(fd);
+        shm_unlink(name.c_str());
+        return nullptr;
+    }
+    void *mem = MAP_FAILED;
+    for (int tries = 0; tries < 200 && mem == MAP_FAILED; ++tries) // a second opener may arrive before the creator's ftruncate
+    {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SharedLane))
+            mem = mmap(nullptr, sizeof(SharedLane), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        else
+            usleep(1000);
+    }
+    close(fd);
+    if (mem == MAP_FAILED)
+        return nullptr;
+    SharedLane *sl = static_cast<SharedLane *>(mem);
+    if (creator)
+    {
+        pthread_mutexattr_t at;
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+        pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST);
+        pthread_mutex_init(&sl->mu, &at);
+        pthread_mutexattr_destroy(&at);
+        sl->nprocs.store(0);
+        sl->ready.store(1, std::memory_order_release);
+    }
+    else
+        for (int tries = 0; tries < 2000 && sl->ready.load(std::memory_order_acquire) != 1; ++tries)
+            usleep(1000);
+    if (sl->ready.load(std::memory_order_acquire) != 1)
+        return nullptr;
+    sl->nprocs.fetch_add(1);
+    g_sharedRegistered.push_back(sl);
+    static bool hooked = false;
+    if (!hooked)
+    {
+        hooked = true;
+        atexit([] {
+            for (SharedLane *l : g_sharedRegistered)
+                l->nprocs.fetch_sub(1);
+        });
+    }
+    return sl;
+}
+
+static LstmLane *lstm_lane(int device)
+{
+    std::lock_guard<std::mutex> lk(g_lanesMu);
+    if (g_lanes.empty())
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            return nullptr;
+        g_lanes.resize((size_t)n);
+    }
+    if (device < 0 || device >= (int)g_lanes.size())
+        return nullptr;
+    if (!g_lanes[(size_t)device])
+    {
+        g_lanes[(size_t)device] = std::make_unique<LstmLane>();
+        g_lanes[(size_t)device]->shared = open_shared_lane(device);
+    }
+    return g_lanes[(size_t)device].get();
+}
+
+// holds the process-shared mutex of a lane while another process is registered on the same GPU
+struct SharedLaneGuard
+{
+    SharedLane *sl = nullptr;
+    explicit SharedLaneGuard(SharedLane *l)
+    {
+        if (l && l->nprocs.load() > 1)
+        {
+            const int rc = pthread_mutex_lock(&l->mu);
+            if (rc == EOWNERDEAD)
+                pthread_mutex_consistent(&l->mu);
+            if (rc == 0 || rc == EOWNERDEAD)
+                sl = l;
+        }
+    }
+    bool held() const { return sl != nullptr; }
+    ~SharedLaneGuard()
+    {
+        if (sl)
+            pthread_mutex_unlock(&sl->mu);
+    }
+};
 
 // --------------------------------------------------------------------------- executor
 static unsigned long long *g_dbg = nullptr; // set only by dmx_debug_igemm_timing
@@ -508,14 +703,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         // spin would then turn it into an error, not a hang). LSTM launches of one device therefore form a lane: each
         // waits for the previous one's completion event, whatever stream or context it came from. (Graph captures - batches
         // below 8, at most 48 spinning workgroups per launch - stay outside: a capture cannot wait on a foreign event.)
-        struct LstmLane
-        {
-            std::mutex mu;
-            hipEvent_t ev = nullptr;
-            bool recorded = false;
-        };
-        static LstmLane lanes[64];
-        LstmLane *lane = !c->capturing && c->m->device >= 0 && c->m->device < 64 ? &lanes[c->m->device] : nullptr;
+        LstmLane *lane = c->capturing ? nullptr : lstm_lane(c->m->device);
         std::unique_lock<std::mutex> laneLock;
         if (lane)
         {
@@ -525,13 +713,22 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
             if (lane->recorded)
                 HIPCHK(hipStreamWaitEvent(s, lane->ev, 0));
         }
-        if (launch_lstm(LstmArgs{a(l.xproj), w(l.whh_w), a(l.out), a(l.sync), c->dStatus, l.B, l.T, l.H}, s) != 0)
+        // several PROCESSES on this GPU (bench.py --backend gloo puts every rank on GPU 0): the in-process lane cannot
+        // order their launches, so they take turns through a process-shared mutex, each waiting for its own launch to
+        // finish before the next process may issue one (host-blocking, only while another process is registered)
+        SharedLaneGuard shared(lane ? lane->shared : nullptr);
+        const int lrc = launch_lstm(LstmArgs{a(l.xproj), w(l.whh_w), a(l.out), a(l.sync), c->dStatus, l.B, l.T, l.H}, s);
+        if (lrc == -2)
+            return fail(DMX_ERR_ARG, "op %s: the %d-segment LSTM launch needs more co-resident workgroups than this device holds", op.name.c_str(), l.B);
+        if (lrc != 0)
             return fail(DMX_ERR_ARG, "internal error: no LSTM kernel for op %s (H = %d)", op.name.c_str(), l.H);
         if (lane)
         {
             HIPCHK(hipEventRecord(lane->ev, s));
             lane->recorded = true;
         }
+        if (shared.held())
+            HIPCHK(hipStreamSynchronize(s));
         break;
     }
     case OP_LOCAL_ATTN:
@@ -725,7 +922,7 @@ extern "C" int dmx_segment_infer(dmx_ctx *c, const float *mix, float *out, int l
         return rc;
     std::vector<float> planar((size_t)(S * 2 * seg));
     HIPCHK(hipMemcpyAsync(planar.data(), c->dA + p->outOff, sizeof(float) * planar.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    DMXCHK(dmx_ctx_sync_checked(c));
     if (layout == DMX_LAYOUT_PLANAR)
         std::memcpy(out, planar.data(), sizeof(float) * planar.size());
     else
@@ -909,8 +1106,10 @@ extern "C" int dmx_track_infer(dmx_ctx *c, const float *audio, int64_t n, int sh
             DMXCHK(copy_piece(k - 1));
     }
     DMXCHK(copy_piece(nBatches - 1));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const int rcSync = dmx_ctx_sync_checked(c);
     HIPCHK(hipStreamSynchronize(c->copyStream));
+    if (rcSync != DMX_OK)
+        return rcSync;
     return DMX_OK;
 }
 
@@ -969,6 +1168,15 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
         const IGemm &g = op.g;
         const double M = (double)g.B * g.P1 * g.P0;
         kernel = cfgNames[g.cfg];
+        if (g.split) // exact bf16 operand-split kernel of the same tile (igemm_split.hip): its own roofline class
+        {
+            static const char *splitNames[kNumTileCfgs] = {"igemm_split_128x128", nullptr, "igemm_split_128x96", nullptr, nullptr, nullptr, nullptr,
+                                                            "igemm_split_64x128", nullptr, "igemm_split_64x64", "igemm_split_64x96", nullptr,
+                                                            nullptr, nullptr, nullptr, "igemm_split_32x128", "igemm_split_32x64", nullptr, nullptr,
+                                                            nullptr, nullptr};
+            if (splitNames[g.cfg])
+                kernel = splitNames[g.cfg];
+        }
         flops = 2.0 * M * g.N * g.K;
         double in = (double)g.B * g.L1 * g.L0 * g.Cin, w = (double)g.N * g.K, out = 0;
         if (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES)

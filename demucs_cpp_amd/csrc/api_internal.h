@@ -4,6 +4,7 @@
 #include "../../include/demucs_hip.h"
 #include "kernels.h"
 
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <memory>
@@ -35,7 +36,8 @@ struct dmx_model
                             // can be replicated onto further devices (dmx_model_clone) without re-reading the file
     size_t blobFloats = 0;  // size of the packed weights (also when pm.blob has been released)
     float *dW = nullptr;
-    unsigned short *dWb = nullptr; // EXPERIMENT (DMX_GEMM=bf16x3): two bf16 planes of the blob, w = w1 + w2, each blobFloats long
+    unsigned short *dWb = nullptr; // two bf16 planes of the blob (GEMM_BF16X3 contexts): w = w1 + w2 by round-to-nearest splits,
+                                   // plane 2 starts at element blobFloats + 512
     int device = 0;
 };
 // uploads `blob` (blobFloats floats) as the weights of `m` on m->device
@@ -77,6 +79,7 @@ struct dmx_ctx
     DevBuf bAudio, bTmp, bMix, bSegOut, bOut;
     float *dStats = nullptr;            // 4 floats
     unsigned *dStatus = nullptr;        // device status word: raised by a kernel whose bounded spin timed out (v3.hip LSTM)
+    unsigned *hStatus = nullptr;        // pinned host copy (dmx_ctx_sync_checked)
     std::vector<hipEvent_t> batchEvents; // progress reporting without host synchronisation of the stream
     // HIP graphs of the batch-1 plan (launch-bound latency path), keyed by the redirected I/O pointers
     struct GraphKey
@@ -95,6 +98,7 @@ struct dmx_ctx
         }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
+    int gemm = 0;      // dmx::GemmMode of every plan of this context (DMX_GEMM_* of the C ABI), fixed at creation
     int graphMode = 1; // env DMX_GRAPH: 0 off, 1 (default) capture the two-stream plans of small batches into HIP graphs
     int fuseIstft = 1; // env DMX_FUSE_ISTFT=0: ISTFT and overlap-add as two kernels through the `frames` tensor (A/B)
     int graphBatch = 0; // batch size the cached graphs were captured for
@@ -103,6 +107,36 @@ struct dmx_ctx
     bool haveLastKey = false;
     ~dmx_ctx();
 };
+
+// bf16 <-> fp32 on the host (round to nearest even; the weight planes of the exact-split GEMM path)
+static inline unsigned short dmx_bf16_rn(float f)
+{
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) // inf / NaN: truncate, keep a NaN a NaN
+        return (unsigned short)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float dmx_bf16_f32(unsigned short h)
+{
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// w = w1 + w2 + (remainder): the two-term round-to-nearest split of the weight planes; returns true when it is exact
+static inline bool dmx_split_weight(float w, unsigned short &w1, unsigned short &w2)
+{
+    w1 = dmx_bf16_rn(w);
+    const float r = w - dmx_bf16_f32(w1); // exact (Sterbenz-like: w1 is w rounded to 8 significant bits)
+    w2 = dmx_bf16_rn(r);
+    return dmx_bf16_f32(w1) + dmx_bf16_f32(w2) == w;
+}
+// D2H of the context's status word behind the work already enqueued + stream synchronisation + test-and-clear:
+// every host-side wait on a context's results goes through this (a cooperative kernel whose bounded spin timed
+// out must never produce silently corrupt stems)
+int dmx_ctx_sync_checked(dmx_ctx *c);
 
 // ---- internal entry points used by engine.cpp
 int dmx_ensure_buf(DevBuf &b, dmx::i64 floats);

@@ -567,7 +567,7 @@ static int device_work(dmx_engine *e, int l, const float *audio, int layout, i64
         HIPCHK(hipEventSynchronize(c->batchEvents[k]));
         post_progress(sh, evItems[k], l, d.dev);
     }
-    HIPCHK(hipStreamSynchronize(c->stream)); // the slab has reached the root (or the root has received every slab)
+    DMXCHK(dmx_ctx_sync_checked(c)); // the slab has reached the root (or the root has received every slab)
     return DMX_OK;
 }
 
@@ -720,7 +720,7 @@ static int device_work_owner(dmx_engine *e, int l, const float *audio, int layou
     }
     if (!rccl)
     {
-        HIPCHK(hipStreamSynchronize(c->stream)); // my tails have landed at their receivers
+        DMXCHK(dmx_ctx_sync_checked(c)); // my tails have landed at their receivers
         {
             std::lock_guard<std::mutex> lk(sh.mu);
             for (const Run &r : runs)
@@ -781,7 +781,7 @@ static int device_work_owner(dmx_engine *e, int l, const float *audio, int layou
         stageFloats += pc.len * pc.rows;
         pieces.push_back(pc);
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    DMXCHK(dmx_ctx_sync_checked(c));
     for (const Piece &pc : pieces)
         for (int r = 0; r < pc.rows; ++r)
             memcpy(out + pc.dst + (i64)r * pc.pitch, d.pinned + pc.stage + (i64)r * pc.len, sizeof(float) * (size_t)pc.len);
@@ -951,6 +951,6 @@ extern "C" int dmx_engine_track_infer(dmx_engine *e, const float *audio, int64_t
                                             M == 1 ? 0 : 2 * m, M == 1 ? 2 * S : 2));
     }
     HIPCHK(hipMemcpyAsync(out, e->out.p, sizeof(float) * (size_t)S * 2 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    DMXCHK(dmx_ctx_sync_checked(c));
     return DMX_OK;
 }

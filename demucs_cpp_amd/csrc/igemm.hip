@@ -31,7 +31,7 @@
 // Alignment contract (checked by the host, dmx_ctx_create): every float4 staging chunk is
 // either entirely inside or entirely outside the valid input, and 16-byte aligned:
 // Cin*L0, Cin*stride0, Cin*pad0, seg0, K, xBatchStride are multiples of 4 elements.
-#include "kernels.h"
+#include "igemm_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -76,33 +76,6 @@
 namespace dmx
 {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float gelu_f(float v) { return dmx_gelu(v); }
-// 1 / (1 + e^-v) with v_rcp_f32 (1 ulp): the IEEE division expands to ~10 VALU instructions, and a GLU
-// epilogue evaluates one sigmoid per output
-__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ __forceinline__ float f4c(const f32x4 &v, int c) { return v[c]; }
-// `ok ? *ptr : zero` as written selects between a global pointer and a private temporary and loads
-// through a FLAT pointer (plus a scratch slot); select the address against the zero page instead
-__device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *zero)
-{
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? ptr : zero);
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-
-// global -> LDS load of 16 bytes per lane (global_load_lds_dwordx4): lane l writes lds_base + 16 l; lds_base is
-// wave-uniform (M0). The builtin exists in the device pass only.
-__device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_base)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
-#else
-    (void)gptr;
-    (void)lds_base;
-#endif
-}
-
 // LIN: "linear layer" addressing - one contiguous run of K floats per row (S1 == 1, no padding, K a
 // multiple of the K-tile): the staging addresses of a row just advance by one K-tile per iteration, no
 // per-tile bounds checks, tap bookkeeping or pointer selects (transformer linears, 1x1 rewrites).
@@ -140,108 +113,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // workgroup -> tile. Workgroup b is dispatched to XCD b % 8 (observed; used for speed only). With the
-    // XCD-aware map all column tiles of a row tile run on the same XCD right after one another, so the
-    // A row block is fetched from HBM / Infinity Cache once and re-read from that XCD's 4 MB L2, and the
-    // 64 workgroups resident on an XCD form a (few row tiles) x (all column tiles) patch that shares both
-    // operands' k-slices. Row tiles are dealt round-robin to the XCDs (balanced to one tile).
     unsigned tileM, tileN;
-    if (p.xcdMap)
-    {
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const unsigned mi = j / p.tilesN;
-        tileN = j - mi * p.tilesN;
-        tileM = mi * 8u + xcd;
-        if (tileM >= p.tilesM)
-            return; // whole workgroup, before any barrier
-    }
-    else
-    {
-        tileN = blockIdx.x / p.tilesM;
-        tileM = blockIdx.x - tileN * p.tilesM;
-    }
+    if (!tile_of_block(p, tileM, tileN)) // XCD-aware workgroup -> tile map (igemm_common.h)
+        return;                          // whole workgroup, before any barrier
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
 
     for (int r = tid; r < BM; r += NT)
-    {
-        const i64 m = m0 + r;
-        int4 ri = make_int4(0, 0, 0, -1);
-        if (m < p.M)
-        {
-            // magic-number divisions (three 64-bit software divides per row were a visible part of the
-            // per-tile prologue)
-            const unsigned mu = (unsigned)m;
-            const unsigned t = p.dP0.magic ? (__umulhi(mu, p.dP0.magic) >> p.dP0.shift) : (mu >> p.dP0.shift);
-            const int p0 = (int)(mu - t * (unsigned)p.P0);
-            const unsigned b = p.dP1.magic ? (__umulhi(t, p.dP1.magic) >> p.dP1.shift) : (t >> p.dP1.shift);
-            const int p1 = (int)(t - b * (unsigned)p.P1);
-            ri = make_int4((int)b, p1, p0, (int)b * p.G0 + (p.G0 > 1 ? p0 : 0));
-        }
-        rowinfo[r] = ri;
-    }
+        rowinfo[r] = row_info(p, m0 + r);
     __syncthreads();
 
-    // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slane`
+    // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slaneK` (igemm_common.h StageWalk)
     const int slane = tid % LPR, srow = tid / LPR;
     const int slaneK = slane ^ ((srow / RPB) % LPR); // k-quad this lane fetches (LDS slot `slane` of its rows)
-    const i64 rowLen = (i64)p.L0 * p.Cin;
-    const int rowLenI = (int)rowLen;
-    const float *aRow[AR]; // X + b*xBS + in1_0*rowLen + e0  (tap s1 = 0, k = 0)
-    bool aRowOk[AR];
-    // General (conv) addressing: validity of a staged chunk depends only on (row, tap), tap c = k / Cin =
-    // s1 * (seg0 / Cin) + (tap along axis 0) - padding starts and ends at whole taps - so each row carries ONE
-    // bit per tap, computed here once per tile; the K walk then tests a bit instead of re-deriving four range
-    // checks per row and K-tile (measured: the address arithmetic of the general path cost the 3x3 rewrites 10 %).
-    unsigned aTapMask[AR];
-    float aMean[AR], aScale[AR];
-    const int taps0 = p.seg0 / p.Cin;
-#pragma unroll
-    for (int i = 0; i < AR; ++i)
-    {
-        const int4 ri = rowinfo[srow + i * RP];
-        aRowOk[i] = ri.w >= 0;
-        const int in1_0 = ri.y * p.stride1 - p.pad1;
-        const int e0 = (ri.z * p.stride0 - p.pad0) * p.Cin;
-        aRow[i] = p.X + (i64)ri.x * p.xBS + (i64)in1_0 * rowLen + e0;
-        aTapMask[i] = 0;
-        if (!LIN && aRowOk[i])
-        {
-            unsigned m0bits = 0; // taps along axis 0 whose chunk lies inside the row
-            for (int t0 = 0; t0 < taps0; ++t0)
-            {
-                const int e = e0 + t0 * p.Cin;
-                m0bits |= (e >= 0 && e < rowLenI ? 1u : 0u) << t0;
-            }
-            for (int s = 0; s < p.S1; ++s)
-            {
-                const int in1 = in1_0 + s * p.dil1;
-                if (in1 >= 0 && in1 < p.L1)
-                    aTapMask[i] |= m0bits << (s * taps0);
-            }
-        }
-        aMean[i] = 0.f, aScale[i] = 1.f;
-        if (PRO == PRO_AFFINE && aRowOk[i])
-        {
-            aMean[i] = p.proStats[ri.x * 4];
-            aScale[i] = p.proStats[ri.x * 4 + 1];
-        }
-        if (PRO == PRO_GN_GELU && aRowOk[i])
-        {
-            aMean[i] = p.proStats[ri.w * 4];
-            aScale[i] = p.proStats[ri.w * 4 + 1];
-        }
-    }
-    const float *bRow[BR];
-    bool bRowOk[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i)
-    {
-        const int rl = srow + i * RP;
-        const int n = n0 + rl;
-        bRowOk[i] = rl < BN && n < p.Np;
-        bRow[i] = p.Wt + (i64)(bRowOk[i] ? n : 0) * p.Kp;
-    }
+    StageWalk<AR, BR, 16 * KS, PRO, LIN> w(p, slaneK);
+    w.init([&](int r) { return rowinfo[r]; }, [&](int i) { return srow + i * RP; }, [&](int i) { return srow + i * RP; }, n0, BN);
 
     // staging registers are NATIVE vectors: a float4 (struct) copied whole is lowered to a memcpy through a
     // private-memory alloca that SROA does not split, i.e. the tile would travel global -> scratch -> LDS
@@ -249,164 +135,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
     const int nk16 = p.Kp >> 4;
     const int nk = (nk16 + KS - 1) / KS;
 
-    // Sequential K walk, one tile = 16*KS consecutive k; this lane stages k = kl .. kl+3.
-    // (s1, offb) = conv tap along axis 1 / offset inside its contiguous run, advanced per
-    // lane without division. Addresses of the NEXT tile are computed one iteration ahead
-    // (after the MFMA block), so the loop body starts with nothing but the global loads:
-    //   loads(t+1) ; MFMA(t) ; transform+ds_write(t+1) ; addresses(t+2) ; barrier
-    // Out-of-range chunks point at the zero page: PRO_NONE needs no masking at all.
-    int kl = slaneK * 4, s1 = 0, offb = slaneK * 4;
-    if (p.S1 > 1)
-        while (offb >= p.seg0)
-        {
-            offb -= p.seg0;
-            ++s1;
-        }
-    int tapC = 0, tapOff = slaneK * 4; // tap index kl / Cin and offset inside the tap
-    if (!LIN)
-        while (tapOff >= p.Cin)
-        {
-            tapOff -= p.Cin;
-            ++tapC;
-        }
-    const float *addrA[AR], *addrB[BR], *addrG = p.zero;
-    unsigned maskNext = 0, maskHeld = 0;
-    i64 stepA[AR], stepB[BR]; // LIN: per-row advance (0 for rows that stay on the zero page)
-    bool linInit = false;
-    // addresses of the next tile to fetch, in two halves (the interleaved loop slots them between MFMA groups):
-    // addrs_A = validity + A row addresses, addrs_B = B row addresses + advance of the K walk
-    int segOffCur = 0;
-    unsigned tapBit = 0;
-    // general addressing of the A rows; half = 0 / 1: first / second half of the rows (the tile-wide
-    // quantities are set up with the first half), 2: all rows
-    auto addrs_A_general = [&](int half) {
-        if (half != 1)
-        {
-            maskNext = 0;
-            tapBit = tapC < 32 ? 1u << tapC : 0u; // taps beyond K (k >= K) have no bit in any row mask
-            segOffCur = s1 * p.dil1 * rowLenI + offb; // fits int32 for every layer of the model
-            if (PRO == PRO_GN_GELU)
-                addrG = p.proW + (kl < p.K ? kl : 0);
-        }
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-            if (half == 2 || (i < (AR + 1) / 2) == (half == 0))
-            {
-                const bool ok = (aTapMask[i] & tapBit) != 0u;
-                addrA[i] = ok ? aRow[i] + segOffCur : p.zero;
-                maskNext |= (ok ? 1u : 0u) << i;
-            }
-    };
-    auto addrs_A = [&]() {
-        if (LIN)
-        {
-            if (!linInit)
-            {
-                maskNext = 0;
-#pragma unroll
-                for (int i = 0; i < AR; ++i)
-                {
-                    addrA[i] = aRowOk[i] ? aRow[i] + slaneK * 4 : p.zero;
-                    stepA[i] = aRowOk[i] ? 16 * KS : 0;
-                    maskNext |= (aRowOk[i] ? 1u : 0u) << i;
-                }
-                if (PRO == PRO_GN_GELU)
-                    addrG = p.proW + slaneK * 4;
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < AR; ++i)
-                addrA[i] += stepA[i];
-            if (PRO == PRO_GN_GELU)
-                addrG += 16 * KS;
-            return;
-        }
-        addrs_A_general(2);
-    };
-    auto addrs_B = [&]() {
-        if (LIN)
-        {
-            if (!linInit)
-            {
-                linInit = true;
-#pragma unroll
-                for (int i = 0; i < BR; ++i)
-                {
-                    addrB[i] = bRowOk[i] ? bRow[i] + slaneK * 4 : p.zero;
-                    stepB[i] = bRowOk[i] ? 16 * KS : 0;
-                }
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-                addrB[i] += stepB[i];
-            return;
-        }
-        // B rows advance like a linear layer's. k >= Kp (second half of the last K-tile when Kp is an odd
-        // multiple of 16) reads the next weight row / the zeroed tail of the blob: those k meet A chunks of
-        // the zero page (no tap bit), and 0 x finite adds exactly 0.
-        if (!linInit)
-        {
-            linInit = true;
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-            {
-                addrB[i] = bRowOk[i] ? bRow[i] + slaneK * 4 : p.zero;
-                stepB[i] = bRowOk[i] ? 16 * KS : 0;
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-                addrB[i] += stepB[i];
-        }
-        kl += 16 * KS;
-        offb += 16 * KS;
-        if (p.S1 > 1 && offb >= p.seg0)
-        {
-            offb -= p.seg0;
-            ++s1;
-        }
-        tapOff += 16 * KS;
-        while (tapOff >= p.Cin)
-        {
-            tapOff -= p.Cin;
-            ++tapC;
-        }
-    };
-    auto compute_addrs = [&]() {
-        addrs_A();
-        addrs_B();
-    };
-    // the same work in pieces for the interleaved loop (piece c goes behind MFMA group c of k-chunk 0)
-    auto addr_piece = [&](int c) {
-        if (LIN)
-        {
-            if (c == 0)
-                addrs_A();
-            if (c == 2)
-                addrs_B();
-            return;
-        }
-        if (c < 2)
-            addrs_A_general(c);
-        if (c == 2)
-            addrs_B();
-    };
+    // Addresses of the NEXT tile are computed one iteration ahead (after the MFMA block), so the loop body starts with
+    // nothing but the global loads:  loads(t+1) ; MFMA(t) ; transform+ds_write(t+1) ; addresses(t+2) ; barrier
+    unsigned maskHeld = 0;
+    auto compute_addrs = [&]() { w.compute_addrs(); };
+    auto addr_piece = [&](int c) { w.addr_piece(c); };
     auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            aReg[i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
+            aReg[i] = *reinterpret_cast<const f32x4 *>(w.addrA[i]);
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            bReg[i] = *reinterpret_cast<const f32x4 *>(addrB[i]);
+            bReg[i] = *reinterpret_cast<const f32x4 *>(w.addrB[i]);
         if (PRO == PRO_GN_GELU)
         {
-            gW = *reinterpret_cast<const f32x4 *>(addrG);
-            gB = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
+            gW = *reinterpret_cast<const f32x4 *>(w.addrG);
+            gB = *reinterpret_cast<const f32x4 *>(w.addrG + (p.proB - p.proW));
         }
-        maskHeld = maskNext;
+        maskHeld = w.maskNext;
     };
     // prologue transform (+ zero fill where a transform would make padding non-zero) + LDS write.
     // LDS image [row][slot] float4, slot = k-quad ^ f(row): this lane holds k-quad slaneK = slane ^ f(row), i.e. slot `slane`.
@@ -414,27 +160,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
 #pragma unroll
         for (int i = 0; i < AR; ++i)
         {
-            f32x4 v = aReg[i];
-            if (PRO != PRO_NONE)
-            {
-                const bool ok = (maskHeld >> i) & 1u;
-                if (PRO == PRO_AFFINE)
-                {
-                    v.x = (v.x - aMean[i]) * aScale[i];
-                    v.y = (v.y - aMean[i]) * aScale[i];
-                    v.z = (v.z - aMean[i]) * aScale[i];
-                    v.w = (v.w - aMean[i]) * aScale[i];
-                }
-                if (PRO == PRO_GN_GELU)
-                {
-                    v.x = gelu_f((v.x - aMean[i]) * aScale[i] * gW.x + gB.x);
-                    v.y = gelu_f((v.y - aMean[i]) * aScale[i] * gW.y + gB.y);
-                    v.z = gelu_f((v.z - aMean[i]) * aScale[i] * gW.z + gB.z);
-                    v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW.w + gB.w);
-                }
-                if (!ok)
-                    v = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const f32x4 v = w.transform(aReg[i], i, (maskHeld >> i) & 1u, gW, gB);
             *reinterpret_cast<f32x4 *>(&bufA(buf)[srow + i * RP][slane]) = v;
         }
 #pragma unroll
@@ -451,11 +177,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 if ((i < AH) == (piece == 0))
-                    aReg[i] = *reinterpret_cast<const f32x4 *>(addrA[i]);
+                    aReg[i] = *reinterpret_cast<const f32x4 *>(w.addrA[i]);
             if (PRO == PRO_GN_GELU && piece == 0)
             {
-                gW = *reinterpret_cast<const f32x4 *>(addrG);
-                gB = *reinterpret_cast<const f32x4 *>(addrG + (p.proB - p.proW));
+                gW = *reinterpret_cast<const f32x4 *>(w.addrG);
+                gB = *reinterpret_cast<const f32x4 *>(w.addrG + (p.proB - p.proW));
             }
         }
         else
@@ -463,7 +189,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
 #pragma unroll
             for (int i = 0; i < BR; ++i)
                 if ((i < BH) == (piece == 2))
-                    bReg[i] = *reinterpret_cast<const f32x4 *>(addrB[i]);
+                    bReg[i] = *reinterpret_cast<const f32x4 *>(w.addrB[i]);
         }
     };
     auto store_piece = [&](int buf, int piece) {
@@ -473,27 +199,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
             for (int i = 0; i < AR; ++i)
                 if ((i < AH) == (piece == 0))
                 {
-                    f32x4 v = aReg[i];
-                    if (PRO != PRO_NONE)
-                    {
-                        const bool ok = (maskHeld >> i) & 1u;
-                        if (PRO == PRO_AFFINE)
-                        {
-                            v.x = (v.x - aMean[i]) * aScale[i];
-                            v.y = (v.y - aMean[i]) * aScale[i];
-                            v.z = (v.z - aMean[i]) * aScale[i];
-                            v.w = (v.w - aMean[i]) * aScale[i];
-                        }
-                        if (PRO == PRO_GN_GELU)
-                        {
-                            v.x = gelu_f((v.x - aMean[i]) * aScale[i] * gW.x + gB.x);
-                            v.y = gelu_f((v.y - aMean[i]) * aScale[i] * gW.y + gB.y);
-                            v.z = gelu_f((v.z - aMean[i]) * aScale[i] * gW.z + gB.z);
-                            v.w = gelu_f((v.w - aMean[i]) * aScale[i] * gW.w + gB.w);
-                        }
-                        if (!ok)
-                            v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                    const f32x4 v = w.transform(aReg[i], i, (maskHeld >> i) & 1u, gW, gB);
                     *reinterpret_cast<f32x4 *>(&bufA(buf)[srow + i * RP][slane]) = v;
                 }
         }
@@ -513,14 +219,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 if ((i < AH) == (piece == 0))
-                    load_to_lds_b128(addrA[i], &bufA(buf)[wave * (64 / LPR) + i * RP][0]);
+                    load_to_lds_b128(w.addrA[i], &bufA(buf)[wave * (64 / LPR) + i * RP][0]);
         }
         else
         {
 #pragma unroll
             for (int i = 0; i < BR; ++i)
                 if ((i < BH) == (piece == 2))
-                    load_to_lds_b128(addrB[i], &bufB(buf)[wave * (64 / LPR) + i * RP][0]);
+                    load_to_lds_b128(w.addrB[i], &bufB(buf)[wave * (64 / LPR) + i * RP][0]);
         }
     };
 
@@ -616,7 +322,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
                 if (c == 1)
                     read_frags(CUR, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
                 if (c == 3)
-                    maskHeld = maskNext; // tile kt+1 is written out: from here on the validity of tile kt+2
+                    maskHeld = w.maskNext; // tile kt+1 is written out: from here on the validity of tile kt+2
                 __builtin_amdgcn_sched_barrier(0);
             }
             // DIRECT: this wave's part of tile kt+1 must have LANDED in LDS before the barrier publishes it. The
@@ -716,246 +422,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
         return;
     }
 #endif
-    // ------------------------------------------------------------------ epilogue
-    // The MFMAs were issued with the operands swapped (weights as A, activations as B), so each
-    // accumulator holds C^T: lane (l15, kq) owns row m = tile row 16 i + l15 and the 4 CONSECUTIVE
-    // channels n = 16 j + 4 kq + {0..3} -> one float4 global access per fragment, one row-info
-    // lookup per row fragment, 2-step cross-lane reduction for the row statistics.
-    const bool wantStats = p.rowstat != nullptr;
-    const int colBase = n0 + wn * (WNF * 16) + 4 * kq;
-    float4 biasv[WNF], scalev[WNF], gnWv[WNF], gnBv[WNF];
-    int trR[WNF], trC[WNF]; // EPI_TRCONV: column n -> (phase r, channel co); Cout % 4 == 0
-#pragma unroll
-    for (int j = 0; j < WNF; ++j)
-    {
-        const int n = colBase + j * 16;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        biasv[j] = ld4z(p.bias + n, n < p.N, p.zero);
-        scalev[j] = gnWv[j] = gnBv[j] = z;
-        trR[j] = trC[j] = 0;
-        if (EPI == EPI_TRCONV)
-        {
-            trR[j] = n / p.Cout;
-            trC[j] = n - trR[j] * p.Cout;
-        }
-        if (EPI == EPI_SCALE_RES && n < p.N)
-            scalev[j] = *reinterpret_cast<const float4 *>(p.scale + n);
-        if (EPI == EPI_GN_GLU_SCALE_RES && n < p.N)
-        {
-            gnWv[j] = *reinterpret_cast<const float4 *>(p.epiW + n);
-            gnBv[j] = *reinterpret_cast<const float4 *>(p.epiB + n);
-            if ((j & 1) == 0)
-                scalev[j] = *reinterpret_cast<const float4 *>(p.scale + (n >> 5) * 16 + (n & 15));
-        }
-    }
-
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-    {
-        const int rl = wm * (WMF * 16) + i * 16 + l15;
-        const int4 ri = rowinfo[rl];
-        const bool rowOk = ri.w >= 0;
-        const i64 m = m0 + rl;
-        float s = 0.f, ss = 0.f;
-        // residual operands of the whole row are loaded FIRST (independent loads in flight), then
-        // combined and stored: res may alias Y element-wise (in-place updates), every element is read
-        // before the same lane overwrites it.
-        float4 resv[WNF];
-#pragma unroll
-        for (int j = 0; j < WNF; ++j)
-            resv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
-        {
-            if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
-            {
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                {
-                    const int n = colBase + j * 16;
-                    if (rowOk && n < p.N)
-                        resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + n);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-            {
-                const int n = colBase + j * 16;
-                if (rowOk && n < p.N)
-                {
-                    float4 v = make_float4(acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
-                                           acc[i][j][3] + biasv[j].w);
-                    if (EPI == EPI_LINEAR)
-                    {
-                        if (p.act)
-                            v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-                        v.x += resv[j].x, v.y += resv[j].y, v.z += resv[j].z, v.w += resv[j].w;
-                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
-                    }
-                    else if (EPI == EPI_SCALE_RES)
-                    {
-                        v = make_float4(resv[j].x + v.x * scalev[j].x, resv[j].y + v.y * scalev[j].y, resv[j].z + v.z * scalev[j].z,
-                                        resv[j].w + v.w * scalev[j].w);
-                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
-                    }
-                    if (EPI == EPI_STATS_FACT)
-                    {
-                        // factorised statistics (plan.h): columns < hid are L a (squares), column hid is the row
-                        // sum of the full product, column hid+1 half of the remaining second-moment terms
-                        const int hid = p.Cout;
-                        const float vr[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                            const int nn = n + r;
-                            ss += nn < hid ? vr[r] * vr[r] : (nn == hid + 1 ? 2.0f * vr[r] : 0.f);
-                            s += nn == hid ? vr[r] : 0.f;
-                        }
-                    }
-                    else
-                    {
-                        s += (v.x + v.y) + (v.z + v.w);
-                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                    }
-                }
-            }
-            if (wantStats)
-            {
-                s += __shfl_xor(s, 16);
-                ss += __shfl_xor(ss, 16);
-                s += __shfl_xor(s, 32);
-                ss += __shfl_xor(ss, 32);
-                if (kq == 0)
-                {
-                    rsum[rl][wn].x = s; // member-wise: a whole-struct store goes through a private-memory temporary
-                    rsum[rl][wn].y = ss;
-                }
-            }
-        }
-        else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
-        {
-            if constexpr (WNF % 2 == 0)
-            {
-                float mean = 0.f, sc = 1.f;
-                if (EPI == EPI_GN_GLU_SCALE_RES && rowOk)
-                {
-                    mean = p.epiStats[ri.w * 4];
-                    sc = p.epiStats[ri.w * 4 + 1];
-                }
-#pragma unroll
-                for (int j = 0; j < WNF; j += 2)
-                {
-                    const int na = colBase + j * 16;
-                    const int c = (na >> 5) * 16 + (na & 15);
-                    if (rowOk && na + 16 < p.N)
-                    {
-                        if (EPI == EPI_GN_GLU_SCALE_RES)
-                            resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + c);
-                        else if (p.table)
-                        {
-                            const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)ri.z * (p.N >> 1) + c);
-                            resv[j] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < WNF; j += 2)
-                {
-                    const int na = colBase + j * 16, nb = na + 16;
-                    if (rowOk && nb < p.N)
-                    {
-                        const int c = (na >> 5) * 16 + (na & 15);
-                        const float av[4] = {acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
-                                             acc[i][j][3] + biasv[j].w};
-                        const float gv[4] = {acc[i][j + 1][0] + biasv[j + 1].x, acc[i][j + 1][1] + biasv[j + 1].y,
-                                             acc[i][j + 1][2] + biasv[j + 1].z, acc[i][j + 1][3] + biasv[j + 1].w};
-                        const float rv[4] = {resv[j].x, resv[j].y, resv[j].z, resv[j].w};
-                        float ov[4];
-                        if (EPI == EPI_GN_GLU_SCALE_RES)
-                        {
-                            const float gw[4] = {gnWv[j].x, gnWv[j].y, gnWv[j].z, gnWv[j].w};
-                            const float gb[4] = {gnBv[j].x, gnBv[j].y, gnBv[j].z, gnBv[j].w};
-                            const float hw[4] = {gnWv[j + 1].x, gnWv[j + 1].y, gnWv[j + 1].z, gnWv[j + 1].w};
-                            const float hb[4] = {gnBv[j + 1].x, gnBv[j + 1].y, gnBv[j + 1].z, gnBv[j + 1].w};
-                            const float sv[4] = {scalev[j].x, scalev[j].y, scalev[j].z, scalev[j].w};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                            {
-                                const float a = (av[r] - mean) * sc * gw[r] + gb[r];
-                                const float g = (gv[r] - mean) * sc * hw[r] + hb[r];
-                                ov[r] = rv[r] + sv[r] * (a * sigmoid_f(g));
-                            }
-                        }
-                        else
-                        {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                ov[r] = av[r] * sigmoid_f(gv[r]) + rv[r];
-                        }
-                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                    }
-                }
-            }
-        }
-        else // EPI_TRCONV
-        {
-            i64 offs[WNF];
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-            {
-                const int n = colBase + j * 16;
-                const int jj = p.trS * ri.z + trR[j] - p.trOff;
-                offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j] : -1;
-            }
-            if (p.res)
-            {
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    if (offs[j] >= 0)
-                        resv[j] = *reinterpret_cast<const float4 *>(p.res + offs[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-                if (offs[j] >= 0)
-                {
-                    float4 v = make_float4(acc[i][j][0] + biasv[j].x, acc[i][j][1] + biasv[j].y, acc[i][j][2] + biasv[j].z,
-                                           acc[i][j][3] + biasv[j].w);
-                    if (p.act)
-                        v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-                    v.x += resv[j].x, v.y += resv[j].y, v.z += resv[j].z, v.w += resv[j].w;
-                    *reinterpret_cast<float4 *>(p.Y + offs[j]) = v;
-                }
-        }
-    }
-    if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
-        if (wantStats)
-        {
-            __syncthreads();
-            for (int r = tid; r < BM; r += NT)
-            {
-                const i64 m = m0 + r;
-                if (m < p.M)
-                {
-                    float s = 0.f, ss = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WAVES_N; ++w)
-                    {
-                        s += rsum[r][w].x;
-                        ss += rsum[r][w].y;
-                    }
-                    float *dst = p.rowstat + (m * p.NB + tileN) * 2;
-                    dst[0] = s;
-                    dst[1] = ss;
-                }
-            }
-        }
-}
-
-template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
-static bool is_linear(const GemmArgs &a)
-{
-    return PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2 && a.S1 == 1 && a.pad0 == 0 &&
-           a.seg0 == a.K && a.K == a.Kp && a.K % (16 * KS) == 0 && a.Np % 4 == 0 &&
-           (i64)(a.P0 - 1) * a.stride0 * a.Cin + a.seg0 <= (i64)a.L0 * a.Cin && a.P1 == a.L1 && a.stride1 == 1 && a.pad1 == 0;
+    // ------------------------------------------------------------------ epilogue (igemm_common.h)
+    igemm_epilogue<WAVES_N, WMF, WNF, EPI, NT>(p, acc, [&](int r) { return rowinfo[r]; }, rsum, m0, n0, tileN, wm, wn, BM);
 }
 
 template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
@@ -974,7 +442,7 @@ static void launch_one(const GemmArgs &a0, hipStream_t s)
     constexpr bool CAN_IL = KS == 2;
     if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2)
     {
-        if (linOn && is_linear<WM_, WN_, MF, NF, KS, PRO, EPI>(a))
+        if (linOn && KS == 2 && gemm_is_linear(a, PRO, EPI, 16 * KS))
         {
             if (CAN_IL && ilOn)
                 hipLaunchKernelGGL((igemm_kernel<WM_, WN_, MF, NF, KS, PRO, EPI, true, CAN_IL>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, a);

@@ -74,8 +74,10 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
 // linear layers on a 256x128 tile with four waves of 128x64 (igemm_lin256.hip); -1 when the op is not a plain linear layer
 int launch_igemm_lin256(const GemmArgs &a, hipStream_t s, bool dry = false);
-// EXPERIMENT (DMX_GEMM=bf16x3): the same tiles with exact bf16 operand splits on the bf16 matrix pipe; -1 = not available
+// GEMM_BF16X3 contexts: the same tiles with exact bf16 operand splits on the bf16 matrix pipe (igemm_split.hip); -1 = not available
 int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
+// the kernels' three-term activation split applied to an array: planes [3][n] bf16 bit patterns (unit test of the split)
+void launch_split3_debug(const float *d_x, i64 n, unsigned short *d_planes, hipStream_t s);
 
 struct ReduceArgs
 {
@@ -193,7 +195,7 @@ struct LstmArgs
     unsigned *status; // raised when a bounded spin timed out (checked by dmx_ctx_synchronize)
     int B, T, H;
 };
-int launch_lstm(const LstmArgs &a, hipStream_t s); // -1: unsupported hidden size
+int launch_lstm(const LstmArgs &a, hipStream_t s); // -1: unsupported hidden size; -2: the grid of spinning workgroups cannot be co-resident on this device
 struct LocalAttnArgs
 {
     const float *qkvd;

@@ -170,7 +170,8 @@ struct Builder
     Plan &pl;
     i64 top = 0;
     i64 redScratch[2] = {-1, -1};
-    Builder(const PackedModel &m, Plan &p) : pm(m), pl(p) {}
+    PlanOpts opts;
+    Builder(const PackedModel &m, Plan &p, const PlanOpts &o) : pm(m), pl(p), opts(o) { pl.gemm = o.gemm; }
 
     i64 alloc(i64 n)
     {
@@ -207,9 +208,10 @@ struct Builder
         // plain linear layers that keep the 128x128 tile (i.e. enough rows to fill the chip a few times over) run on the
         // 256x128 / four-wave kernel (igemm_lin256.hip; same conditions as its lin256_ok). DMX_LIN256=0 switches it off (A/B).
         {
-            const char *e = getenv("DMX_LIN256"), *ge = getenv("DMX_GEMM");
-            // (the operand-split experiment has no 256x128 form: its linears stay on the tiles igemm_split.hip instantiates)
-            const bool on = (!e || atoi(e) != 0) && !(ge && std::string(ge) == "bf16x3");
+            const char *e = getenv("DMX_LIN256");
+            const bool splitMode = opts.gemm == GEMM_BF16X3;
+            // (the operand-split path has no 256x128 form: its linears stay on the tiles igemm_split.hip instantiates)
+            const bool on = (!e || atoi(e) != 0) && !splitMode;
             const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.S1 == 1 && g.pad0 == 0 &&
                              g.seg0 == g.K && g.K == g.Kp && g.K % 16 == 0 && g.N % 4 == 0 &&
                              (i64)(g.P0 - 1) * g.stride0 * g.Cin + g.seg0 <= (i64)g.L0 * g.Cin && g.P1 == g.L1 && g.stride1 == 1 && g.pad1 == 0 &&
@@ -228,8 +230,8 @@ struct Builder
             // segments; longer K stays on the interleaved 32-deep loop (decoder.3.rewrite, K = 432: 121 vs 118.7). Same column
             // decomposition and k order: identical bits. DMX_SHORTK=0 switches it off (A/B).
             const char *sk = getenv("DMX_SHORTK");
-            const bool splitExp = ge && std::string(ge) == "bf16x3"; // the operand-split experiment keeps the tiles it instantiates
-            if ((!sk || atoi(sk) != 0) && !splitExp && g.cfg == 2 && g.rowstat < 0 && g.pro == PRO_NONE &&
+            // (the operand-split path keeps the tiles it instantiates)
+            if ((!sk || atoi(sk) != 0) && !splitMode && g.cfg == 2 && g.rowstat < 0 && g.pro == PRO_NONE &&
                 (g.epi == EPI_LINEAR || g.epi == EPI_GLU || g.epi == EPI_TRCONV) && g.K <= 160 && M >= 65536)
                 g.cfg = 20;
         }
@@ -349,14 +351,14 @@ struct Builder
 };
 } // namespace
 
-void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl)
+void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts &opts)
 {
     if (pm.arch == 3)
     {
-        build_plan_v3(pm, seg, B, pl);
+        build_plan_v3(pm, seg, B, pl, opts);
         return;
     }
-    Builder b(pm, pl);
+    Builder b(pm, pl, opts);
     pl.B = B;
     pl.geo = make_geo(seg);
     pl.S = pm.n_sources;
@@ -990,9 +992,9 @@ i64 lstm_xchg_floats(int B, int T, int H)
     return x > lstm_sync_floats(B, H) ? x : lstm_sync_floats(B, H);
 }
 
-void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl)
+void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts &opts)
 {
-    Builder b(pm, pl);
+    Builder b(pm, pl, opts);
     pl.B = B;
     pl.geo = make_geo(seg);
     pl.S = 4;

@@ -111,7 +111,7 @@ struct IGemm
     int trS, trOff;           // EPI_TRCONV: n = (r, co), r < trS; output position j = trS*p0 + r - trOff
                               // (k8/s4 with the 2-sample crop: 4, 2; v3's uncropped k8/s4: 4, 0; k4/s2: 2, 0)
     int cfg;                  // tile configuration index (engine)
-    int split;                // EXPERIMENT (DMX_GEMM=bf16x3, api.cpp): run on the exact-split bf16 kernel (igemm_split.hip)
+    int split;                // GEMM_BF16X3 contexts (api.cpp split_ok): run on the exact-split bf16 kernel (igemm_split.hip)
 };
 
 struct StatsReduce
@@ -330,9 +330,21 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi);
 // bit-identical for any batching / sharding of segments
 int choose_cfg(i64 M1, int N, bool paired);
 
+// how the MFMA-bound convs / linears (and, where built, attention) form their fp32 products
+enum GemmMode
+{
+    GEMM_F32 = 0,    // v_mfma_f32_16x16x4_f32: fp32 operands, one k-ordered fmaf chain per output
+    GEMM_BF16X3 = 1, // exact operand splits a = a1 + a2 + a3, w = w1 + w2 (bf16 terms) on the bf16 matrix pipe, fp32 accumulate
+};
+struct PlanOpts
+{
+    int gemm = GEMM_F32;
+};
+
 struct Plan
 {
     int B = 1;
+    int gemm = GEMM_F32; // PlanOpts::gemm the plan was built for (tile rules differ: plan.cpp finish())
     Geo geo;
     int S = 4, D = 512;
     i64 arenaFloats = 0;
@@ -346,8 +358,8 @@ struct Plan
 // model_pack.cpp
 bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err);
 // plan.cpp (v4) / plan_v3.cpp (v3, dispatched from build_plan on pm.arch)
-void build_plan(const PackedModel &pm, i64 seg, int B, Plan &plan);
-void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &plan);
+void build_plan(const PackedModel &pm, i64 seg, int B, Plan &plan, const PlanOpts &opts = PlanOpts());
+void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &plan, const PlanOpts &opts = PlanOpts());
 // arena ranges [lo, hi) an op reads / writes (conservative hulls); constants and W space excluded
 struct Range
 {

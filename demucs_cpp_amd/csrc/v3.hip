@@ -4,6 +4,7 @@
 //   /root/reference/src/layers.hpp:125-225 (generalized_group_norm), src/lstm.cpp:68-147 (lstm_forward),
 //   src/layers.cpp:533-721 (local_attention).
 #include "kernels.h"
+#include <algorithm>
 #include <string>
 
 namespace dmx
@@ -430,16 +431,39 @@ __global__ __launch_bounds__(64 * NW) void lstm_x4_kernel(const LstmArgs p)
     }
 }
 
+// The recurrence kernels spin on partner workgroups, so every workgroup of a launch must be able to be resident at once:
+// the grid is checked against (occupancy of this instantiation) x (compute units) of the current device, minus a margin
+// of one workgroup per CU (the occupancy API can be one block per CU high, MI355X_MICROARCH.md "Correctness boundaries").
+template <typename K>
+static bool lstm_grid_fits(K kernel, unsigned blocks, int threads)
+{
+    int dev = 0, perCu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, 0) != hipSuccess)
+        return false;
+    const long cap = (long)std::max(perCu - 1, 1) * prop.multiProcessorCount;
+    return (long)blocks <= cap;
+}
 template <int H, int FR, int NW>
-static void launch_lstm_t(const LstmArgs &a, hipStream_t s, bool x4)
+static int launch_lstm_t(const LstmArgs &a, hipStream_t s, bool x4)
 {
     constexpr int P = H / (4 * FR * NW);
     const int nGroups = 2 * ((a.B + 15) / 16);
     const unsigned blocks = 8u * P * (unsigned)((nGroups + 7) / 8);
+    static int fitsUpTo[2] = {0, 0}; // largest grid already checked, per kernel form (the check costs a runtime query)
+    if ((int)blocks > fitsUpTo[x4 ? 1 : 0])
+    {
+        const bool ok = x4 ? lstm_grid_fits(lstm_x4_kernel<H, FR, NW>, blocks, 64 * NW) : lstm_grid_fits(lstm_kernel<H, FR, NW>, blocks, 64 * NW);
+        if (!ok)
+            return -2;
+        fitsUpTo[x4 ? 1 : 0] = (int)blocks;
+    }
     if (x4)
         hipLaunchKernelGGL((lstm_x4_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
     else
         hipLaunchKernelGGL((lstm_kernel<H, FR, NW>), dim3(blocks), dim3(64 * NW), 0, s, a);
+    return 0;
 }
 
 int launch_lstm(const LstmArgs &a, hipStream_t s)
@@ -459,12 +483,10 @@ int launch_lstm(const LstmArgs &a, hipStream_t s)
     // previous one's h has crossed the chip); the price is twice the workgroups polling the same granules
     static const int nw = getenv("DMX_LSTM_WAVES") ? atoi(getenv("DMX_LSTM_WAVES")) : 4;
     if (a.H == 192)
-        nw == 8 ? launch_lstm_t<192, 1, 8>(a, s, x4) : launch_lstm_t<192, 1, 4>(a, s, x4);
-    else if (a.H == 384)
-        nw == 8 ? launch_lstm_t<384, 1, 8>(a, s, x4) : launch_lstm_t<384, 1, 4>(a, s, x4);
-    else
-        return -1;
-    return 0;
+        return nw == 8 ? launch_lstm_t<192, 1, 8>(a, s, x4) : launch_lstm_t<192, 1, 4>(a, s, x4);
+    if (a.H == 384)
+        return nw == 8 ? launch_lstm_t<384, 1, 8>(a, s, x4) : launch_lstm_t<384, 1, 4>(a, s, x4);
+    return -1;
 }
 
 // --------------------------------------------------------------------------- LocalState attention core

@@ -75,6 +75,23 @@ extern "C"
      * (src/model.hpp:569-647, src/dsp.hpp:20-101) for `max_batch` segments in flight,
      * allocated once in HBM. segment_samples = 0 selects DMX_SEGMENT_SAMPLES. */
     int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out);
+    /* How a context forms the fp32 products of its convolutions / linear layers (the reference does them in fp32 through
+     * Eigen's GEMM, src/conv.hpp:71-524, src/layers.cpp:426-440). Both modes take and return fp32 and keep every other
+     * operation (normalisations, activations, FFTs, reductions) in fp32:
+     *   DMX_GEMM_F32    v_mfma_f32_16x16x4_f32: each output is one k-ordered fp32 fmaf chain;
+     *   DMX_GEMM_BF16X3 exact operand splits on the bf16 matrix pipe: an activation is the sum of three bf16 terms
+     *                   (a = a1 + a2 + a3, round-to-nearest splits: exact for every finite fp32), a weight - an fp16
+     *                   number in the file - of two (w = w1 + w2: exact), and a w is accumulated in fp32 from five exact
+     *                   partial products; the dropped a3 w2 is <= 2^-24 |a w|. MI355X's bf16 MFMA
+     *                   rate is 16x its fp32 MFMA rate. Ops whose weights are not fp16-exact stay on the fp32 kernels.
+     * dmx_ctx_create uses the process default: environment DMX_GEMM=f32|bf16x3 read once, or dmx_set_default_gemm. A
+     * context keeps its mode for life; contexts of both modes may coexist on one model. (No reference counterpart.) */
+#define DMX_GEMM_F32 0
+#define DMX_GEMM_BF16X3 1
+    int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, int max_batch, int gemm, dmx_ctx **out);
+    int dmx_ctx_gemm(const dmx_ctx *c);
+    int dmx_default_gemm(void);
+    int dmx_set_default_gemm(int gemm); /* also what dmx_engine_create gives its contexts */
     void dmx_ctx_free(dmx_ctx *c);
     int64_t dmx_ctx_segment_samples(const dmx_ctx *c);
     int dmx_ctx_max_batch(const dmx_ctx *c);
@@ -209,6 +226,11 @@ extern "C"
     int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, int report_cap);
     /* cycles per K-tile spent in the 5 phases of one igemm op (-DDMX_TIMING builds only)   */
     int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name, double *out6);
+    /* the operand splits of DMX_GEMM_BF16X3, exposed for their unit tests. Weights (pure host function): w[i] -> bf16 bit
+     * patterns w1[i], w2[i]; returns the number of elements with w1 + w2 != w. Activations (runs the kernels' own device
+     * function on `device`): x[i] -> planes[0..n), [n..2n), [2n..3n) = a1, a2, a3; host pointers. */
+    int64_t dmx_debug_split_weights(const float *w, int64_t n, unsigned short *w1, unsigned short *w2);
+    int dmx_debug_split_activations(int device, const float *x, int64_t n, unsigned short *planes);
 
 #ifdef __cplusplus
 }

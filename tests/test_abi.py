@@ -141,3 +141,28 @@ def test_product_does_not_reference_the_oracle():
                     import re
                     for ln in txt.splitlines():
                         assert not re.search(r"(#\s*include|\bimport\b|\bfrom\b|dlopen|CDLL)[^\n]*(oracle|threaded_split)", ln), (os.path.join(dp, f), ln)
+
+
+def test_weight_split_is_exact_for_every_fp16_value(dmx):
+    """DMX_GEMM_BF16X3 (include/demucs_hip.h): a weight - an fp16 number in the dmc4 / dmc6 / dmc3 files
+    (/root/reference/scripts/convert-pth-to-ggml.py:111-140) - is the sum of two bf16 terms by round-to-nearest splits.
+    Pure host function: checked here for EVERY finite fp16 bit pattern (subnormals included - bf16 has the fp32 exponent
+    range), with the bound |w2| <= 2^-8 |w| that makes the dropped a3 w2 product <= 2^-24 |a w|; values that are not
+    fp16-exact are reported (such ops keep the fp32 kernel, api.cpp split_ok)."""
+    h = np.arange(0, 1 << 16, dtype=np.uint16).view(np.float16)
+    w = h[np.isfinite(h)].astype(np.float32)
+    w1, w2, bad = dmx.split_weights(w)
+    assert bad == 0
+    f1 = (w1.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    f2 = (w2.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.array_equal(f1 + f2, w.astype(np.float64))
+    assert (np.abs(f2) <= 2.0 ** -8 * np.abs(w.astype(np.float64))).all()
+    assert (np.abs(f1 - w) <= 2.0 ** -8 * np.abs(w)).all()
+    # derived (non-fp16) values: some need a third term, and the function says so instead of rounding silently
+    v = np.array([1.0 + 2.0 ** -9 + 2.0 ** -20, np.pi, 1e-30, 3.0], np.float32)
+    _, _, bad = dmx.split_weights(v)
+    assert bad == 3
+    # non-finite weights stay non-finite in the first plane
+    w1, _, _ = dmx.split_weights(np.array([np.inf, -np.inf, np.nan], np.float32))
+    t = (w1.astype(np.uint32) << 16).view(np.float32)
+    assert t[0] == np.inf and t[1] == -np.inf and np.isnan(t[2])

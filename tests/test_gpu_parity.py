@@ -23,13 +23,6 @@ SEG_FULL = 343980
 
 
 @pytest.fixture(scope="module")
-def dmx():
-    from demucs_cpp_amd import binding
-    assert binding.device_count() >= 1, "no HIP device: the product has no CPU fallback"
-    return binding
-
-
-@pytest.fixture(scope="module")
 def oracle_threads():
     orc.lib().orc_set_num_threads(min(32, os.cpu_count() or 1))
 
@@ -313,18 +306,21 @@ def test_cli_mt_and_ft_drop_in(dmx, tmp_models, golden_dir, tmp_path):
     assert subprocess.run([exe_ft, str(bag), wav, str(out_ft)], capture_output=True).returncode == 1
 
 
-def test_bench_multi_rank_control_flow_on_one_gpu():
+@pytest.mark.parametrize("model,port", [("4s", 29517), ("v3", 29518), ("ft", 29519)])
+def test_bench_multi_rank_control_flow_on_one_gpu(model, port):
     """bench.py --backend gloo (test mode): two ranks share GPU 0 and gather through host memory; the
     root checks that the double-buffered gather + pipelined overlap-add of all ranks' segments is
     bit-identical to a local recomputation. Covers everything of the N > 1 bench path except the RCCL
-    transport itself (the sharded track path has its own gloo test on CPU)."""
+    transport itself (the sharded track path has its own gloo test on CPU). v3: two PROCESSES issue the
+    cooperative LSTM kernel on one GPU - the launches take turns through the process-shared lane (api.cpp), a raised
+    status word would fail the run. ft: the bag's four models per rank and step, one gather per model."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "2", "--backend", "gloo", "--no-cpu-baseline", "--no-roofline", "--no-single", "--no-track"],
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "2", "--model", model, "--backend", "gloo", "--no-cpu-baseline", "--no-roofline", "--no-single", "--no-track"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "bit-identical to a local recomputation: True" in r.stdout
@@ -332,6 +328,7 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     import json
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["outputs_finite"] and d["scaling"] == "weak"
+    assert d["config"]["models"] == (4 if model == "ft" else 1)
 
 
 def test_stream_schedule_does_not_change_a_bit(dmx, tmp_models, monkeypatch):
@@ -580,16 +577,18 @@ def test_engine_rccl_agrees_before_the_exchange(dmx, tmp_models, monkeypatch):
         eng.close()
 
 
-def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
-    """BASELINE configs[2]: dmx_track_infer on a 4-minute track (10 584 000 samples, 42 segments of 343980,
-    shift 4033) against (a) a NumPy restatement of the overlap-add loop of
-    /root/reference/src/model_apply.cpp:189-246 applied to the per-segment HIP outputs, and (b) the CPU oracle
-    on the first full segment and on the ragged last one (chunk shorter than a segment, weight from 0, Q8)."""
+@pytest.mark.parametrize("ns", [4, 6])
+def test_full_4min_track_end_to_end(ns, dmx, tmp_models, oracle_threads):
+    """BASELINE configs[2] (htdemucs-4s) and the configs[3] workload on one GPU (htdemucs-6s): dmx_track_infer on a
+    4-minute track (10 584 000 samples, 42 segments of 343980, shift 4033) against (a) a NumPy restatement of the
+    overlap-add loop of /root/reference/src/model_apply.cpp:189-246 applied to the per-segment HIP outputs, and (b) the
+    CPU oracle on the first full segment and on the ragged last one (chunk shorter than a segment, weight from 0, Q8)."""
     import torch
     n, shift = 240 * 44100, 4033
     seg = SEG_FULL
     audio = (0.1 * np.random.default_rng(1).standard_normal((2, n)) + 0.01).astype(np.float32)
-    m = dmx.Model(tmp_models[4]); ctx = dmx.Context(m, 0, 24)
+    m = dmx.Model(tmp_models[ns]); ctx = dmx.Context(m, 0, 24)
+    assert m.n_sources == ns
     ln, nseg, stride = ctx.track_geometry(n, shift)
     assert (nseg, stride, ln) == (42, 257985, n + 22050 - shift)
     got = ctx.track(audio, shift)
@@ -598,7 +597,7 @@ def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
     d_audio = torch.from_numpy(np.ascontiguousarray(audio.T)).cuda()
     d_stats = torch.zeros(4, device="cuda")
     d_mix = torch.empty((nseg, seg, 2), device="cuda")
-    d_out = torch.empty((nseg, 4, 2, seg), device="cuda")
+    d_out = torch.empty((nseg, ns, 2, seg), device="cuda")
     torch.cuda.synchronize()
     ctx.track_stats_device(d_audio.data_ptr(), n, d_stats.data_ptr())
     ctx.track_gather_device(d_audio.data_ptr(), n, d_stats.data_ptr(), shift, list(range(nseg)), d_mix.data_ptr())
@@ -614,7 +613,7 @@ def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
     # ---- (a) the reference's loop: out += w * chunk_out; sum_w += w; out /= sum_w; trim; de-normalise
     w = np.concatenate([np.arange(1, seg // 2 + 1), np.arange(seg - seg // 2, 0, -1)]).astype(np.float32)
     w = w / w.max()
-    acc = np.zeros((4, 2, ln), np.float32)
+    acc = np.zeros((ns, 2, ln), np.float32)
     sw = np.zeros(ln, np.float32)
     for g in range(nseg):
         off = g * stride
@@ -626,7 +625,7 @@ def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 2e-6, err
     # ---- (b) oracle on segment 0 and on the ragged last segment (its chunk is centred in zeros)
-    om = orc.OracleModel(tmp_models[4])
+    om = orc.OracleModel(tmp_models[ns])
     last_chunk = ln - (nseg - 1) * stride
     assert 0 < last_chunk < seg
     for g in (0, nseg - 1):
@@ -638,6 +637,71 @@ def test_full_4min_track_end_to_end(dmx, tmp_models, oracle_threads):
         assert np.abs(seg_out[g] - o_ref).max() <= TOL * np.abs(o_ref).max()
         pu.assert_local_parity(seg_out[g], o_ref, what=f"segment {g} of the 4-minute track")
     om.close(); ctx.close(); m.close()
+
+
+def test_full_ft_bag_4min_track_over_one_and_eight_logical_devices(dmx, tmp_path, monkeypatch):
+    """BASELINE configs[4] at its full size on the one GPU of this box: four fine-tuned 4-source models x the 42 segments
+    of a 4-minute track = 168 (model, segment) items (/root/reference/cli-apps/demucs_ft.cpp:221-241 x
+    src/model_apply.cpp:189-235), every model with its own shift offset (the successive unseeded rand() % 22050). One
+    device runs them as 8 batches of 21; eight LOGICAL devices get the dealing an 8-GPU node would use - 21 items each =
+    half a model = one batch per device (dmx_engine_partition, asserted) - and the result must be bit-identical: ROOT and
+    OWNER finish over peer copies, and once more with every slab routed through the RCCL send/recv path (DMX_RCCL_SELF).
+    Stem i is checked against a plain dmx_track_infer of model i."""
+    from demucs_cpp_amd.weights import write_synthetic_model
+    paths = []
+    for i, name in enumerate(["drums", "bass", "other", "vocals"]):
+        p = str(tmp_path / f"ggml-model-htdemucs_ft_{name}-4s-f16.bin")
+        write_synthetic_model(p, 4, 70 + i)
+        paths.append(p)
+    n = 240 * 44100
+    audio = (0.1 * np.random.default_rng(5).standard_normal((2, n)) - 0.01).astype(np.float32)
+    parts = dmx.engine_partition([42, 42, 42, 42], 8)
+    assert [sum(g1 - g0 for _, g0, g1 in runs) for runs in parts] == [21] * 8
+    assert parts[0] == [(0, 0, 21)] and parts[1] == [(0, 21, 42)] and parts[7] == [(3, 21, 42)]
+    eng = dmx.Engine(paths, [0], max_batch=21)
+    msgs = []
+    want = eng.track(audio, list(SHIFTS_GLIBC), progress=lambda p, s: msgs.append(p))
+    eng.close()
+    assert np.isfinite(want).all() and msgs and abs(max(msgs) - 1.0) < 1e-6
+    # stem 2 of the bag = stem 2 of model 2 run on its own
+    mi = dmx.Model(paths[2]); ci = dmx.Context(mi, 0, 21)
+    assert np.array_equal(ci.track(audio, SHIFTS_GLIBC[2])[2], want[2])
+    ci.close(); mi.close()
+    eng = dmx.Engine(paths, [0] * 8, max_batch=21)
+    assert eng.n_devices == 8 and eng.n_models == 4 and eng.transport == dmx.TRANSPORT_P2P
+    got = np.zeros_like(want)
+    assert np.array_equal(eng.track(audio, list(SHIFTS_GLIBC), out=got), want)
+    eng.set_finish(dmx.FINISH_OWNER)
+    assert np.array_equal(eng.track(audio, list(SHIFTS_GLIBC), out=got), want)
+    eng.close()
+    monkeypatch.setenv("DMX_RCCL_SELF", "1")
+    eng = dmx.Engine(paths, [0] * 8, max_batch=21, transport=dmx.TRANSPORT_RCCL)
+    assert eng.transport == dmx.TRANSPORT_RCCL
+    assert np.array_equal(eng.track(audio, list(SHIFTS_GLIBC), out=got), want)
+    eng.close()
+
+
+def test_6s_4min_track_over_eight_logical_devices(dmx, tmp_models, monkeypatch):
+    """BASELINE configs[3] at its full size on one GPU: the 42 segments of a 4-minute track of the 6-source model dealt to
+    eight logical devices as 6,5,5,5,5,5,5,6 (asserted), ROOT and OWNER finish and the RCCL self exchange, all
+    bit-identical to dmx_track_infer."""
+    n = 240 * 44100
+    audio = (0.1 * np.random.default_rng(6).standard_normal((2, n)) + 0.02).astype(np.float32)
+    parts = dmx.engine_partition([42], 8)
+    assert [g1 - g0 for ((_, g0, g1),) in parts] == [6, 5, 5, 5, 5, 5, 5, 6]
+    m = dmx.Model(tmp_models[6]); ctx = dmx.Context(m, 0, 6)
+    ref = ctx.track(audio, 4033)
+    ctx.close(); m.close()
+    got = np.zeros_like(ref)
+    eng = dmx.Engine([tmp_models[6]], [0] * 8, max_batch=6)
+    assert np.array_equal(eng.track(audio, [4033], out=got), ref)
+    eng.set_finish(dmx.FINISH_OWNER)
+    assert np.array_equal(eng.track(audio, [4033], out=got), ref)
+    eng.close()
+    monkeypatch.setenv("DMX_RCCL_SELF", "1")
+    eng = dmx.Engine([tmp_models[6]], [0] * 8, max_batch=6, transport=dmx.TRANSPORT_RCCL)
+    assert np.array_equal(eng.track(audio, [4033], out=got), ref)
+    eng.close()
 
 
 @pytest.mark.parametrize("variant", ["dc", "illcond", "initscale"])
@@ -795,6 +859,8 @@ def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp
     DESIGN.md 7.3) against the generic direct kernel it replaces: DMX_K1_RING=0 (off), 1 (the product's rule) and 3 (ring
     on the time branch as well, whatever the size) must give identical bits - full-size segments (walks of 8-56 steps,
     ragged last walk) and a short odd length (T = 9 frames: a walk shorter than the ring)."""
+    if dmx.gemm_mode_name != "f32":
+        pytest.skip("compares fp32-MFMA tile variants / a kernel both modes share: run once, in the f32 pass")
     import torch
     m = dmx.Model(tmp_models[which])
     S = m.n_sources
@@ -820,6 +886,8 @@ def test_lin256_kernel_equals_the_128x128_tile_bitwise(dmx, tmp_models, monkeypa
     tile of igemm.hip they replace at large batches (DMX_LIN256=0): same k-ordered fmaf chain per element and the same
     summation order of the row statistics, so every output bit must agree. 38 segments: enough rows for all its
     variants (LINEAR, LINEAR + GELU, SCALE_RES + row statistics) to be selected; the plan dump confirms they are."""
+    if dmx.gemm_mode_name != "f32":
+        pytest.skip("compares fp32-MFMA tile variants / a kernel both modes share: run once, in the f32 pass")
     import torch
     m = dmx.Model(tmp_models[4])
     B = 38
@@ -851,6 +919,8 @@ def test_short_k_tile_equals_the_128x96_tile_bitwise(which, dmx, tmp_models, mon
     """Short-K ops of the 128x96 tile family (K <= 160: the level-1 1x1 rewrites, the time branch's last k3 rewrite) run on
     a 256x96 tile with 16-deep K-tiles at large batches (plan.cpp); DMX_SHORTK=0 keeps them on the 128x96
     tile. Same column decomposition and k order: identical bits (htdemucs-4s and hdemucs_mmi)."""
+    if dmx.gemm_mode_name != "f32":
+        pytest.skip("compares fp32-MFMA tile variants / a kernel both modes share: run once, in the f32 pass")
     import torch
     m = dmx.Model(tmp_models[which])
     B = 26
@@ -944,54 +1014,87 @@ def test_cli_shards_over_dmx_devices_and_finish_modes(dmx, tmp_models, tmp_path)
         assert np.array_equal(a, b), ("ft", i)
 
 
-def test_split_bf16x3_experiment_matches_oracle_and_golden(tmp_models, golden_dir):
-    """EXPERIMENT, opt-in (DMX_GEMM=bf16x3, csrc/igemm_split.hip): the MFMA-bound convs / linears on the bf16 matrix pipe
-    with EXACT operand splits (a = a1 + a2 + a3, w = w1 + w2, fp32 accumulate). The switch is read once per process, so the
-    checks run in a child: fp64 golden (4- and 6-source), full-size segment with every tap against the oracle incl. the
-    local metrics, batch == singles bitwise, Demucs v3. The error against the fp64 model must not exceed the fp32 MFMA
-    path's by more than 10 % (measured: it is slightly smaller)."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, json
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
-import numpy as np, torch
-import oracle_lib as orc, parity_utils as pu
-from demucs_cpp_amd import binding as dmx
-orc.lib().orc_set_num_threads(min(32, os.cpu_count() or 1))
-m4, m6, m3 = sys.argv[1:4]
-res = {}
-for ns, path in ((4, m4), (6, m6)):
-    g = np.load(f"tests/golden/golden_seg_{ns}s.npz")
-    m = dmx.Model(path); ctx = dmx.Context(m, int(g["seg"]), 1)
-    res[f"fp64_{ns}"] = pu.relerr(ctx.segment(g["mix"]), g["out"])
-    ctx.close(); m.close()
-g = np.load("tests/golden/golden_seg_v3.npz")
-m = dmx.Model(m3); ctx = dmx.Context(m, int(g["seg"]), 1)
-res["fp64_v3"] = pu.relerr(ctx.segment(g["mix"]), g["out"])
-ctx.close(); m.close()
-mix = (0.1 * np.random.default_rng(4).standard_normal((2, 343980))).astype(np.float32)
-m = dmx.Model(m4); ctx = dmx.Context(m, 0, 3); om = orc.OracleModel(m4)
-errs, out, ref = pu.compare_segment(ctx, om, mix)  # asserts the local metrics
-res["oracle_worst"] = max(errs.values())
-mixes = np.stack([mix, mix[::-1].copy(), 0.5 * mix])
-d_mix = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).cuda()
-d_out = torch.zeros((3, 4, 2, 343980), device="cuda")
-torch.cuda.synchronize()
-ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), 3); ctx.synchronize()
-res["batch_bitwise"] = bool(np.array_equal(d_out.cpu().numpy()[0], out))
-print("RESULT " + json.dumps(res))
-'''
-    outs = {}
-    for mode in ("f32", "bf16x3"):
-        r = subprocess.run([sys.executable, "-c", code, tmp_models[4], tmp_models[6], tmp_models[3]], cwd=ROOT,
-                           env=dict(os.environ, DMX_GEMM=mode), capture_output=True, text=True, timeout=1200)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-        import json
-        outs[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    s, f = outs["bf16x3"], outs["f32"]
-    assert s["batch_bitwise"] and f["batch_bitwise"]
-    assert s["oracle_worst"] < TOL
-    for k in ("fp64_4", "fp64_6", "fp64_v3"):
-        assert s[k] < TOL and s[k] <= 1.1 * f[k] + 1e-8, (k, s[k], f[k])
-    print("split vs fp32 errors:", s, f)
+def test_gemm_modes_coexist_in_one_process_and_split_error_is_not_worse(tmp_models, golden_dir):
+    """DMX_GEMM_F32 and DMX_GEMM_BF16X3 contexts on ONE model handle in one process (the mode belongs to the context, not
+    to the process): both against the fp64 golden model - the exact-split path (a = a1 + a2 + a3, w = w1 + w2, five exact
+    partial products per term, fp32 accumulate) must be no further from it than the fp32 fmaf chain is (+10 %); a context
+    keeps its mode when the default changes; an unknown mode is refused."""
+    from demucs_cpp_amd import binding as dmx
+    errs = {}
+    for key, path, gname in ((4, tmp_models[4], "golden_seg_4s.npz"), (6, tmp_models[6], "golden_seg_6s.npz"), (3, tmp_models[3], "golden_seg_v3.npz")):
+        g = np.load(os.path.join(golden_dir, gname))
+        m = dmx.Model(path)
+        cf = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_F32)
+        cs = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_BF16X3)
+        assert (cf.gemm, cs.gemm) == (dmx.GEMM_F32, dmx.GEMM_BF16X3)
+        old = dmx.default_gemm()
+        dmx.set_default_gemm(dmx.GEMM_BF16X3 if old == dmx.GEMM_F32 else dmx.GEMM_F32)
+        of, os_ = cf.segment(g["mix"]), cs.segment(g["mix"])  # interleaved calls: nothing is shared but the weights
+        of2 = cf.segment(g["mix"])
+        dmx.set_default_gemm(old)
+        assert np.array_equal(of, of2)
+        assert not np.array_equal(of, os_)  # two different summation trees: equal bits would mean one mode ran twice
+        ef, es = pu.relerr(of, g["out"]), pu.relerr(os_, g["out"])
+        errs[key] = (ef, es)
+        assert ef < TOL and es < TOL and es <= 1.1 * ef + 1e-8, (key, ef, es)
+        cf.close(); cs.close(); m.close()
+    print("fp64-golden errors (f32 MFMA, bf16x3 split):", errs)
+    m = dmx.Model(tmp_models[4])
+    with pytest.raises(dmx.DmxError):
+        dmx.Context(m, 6000, 1, gemm=7)
+    m.close()
+
+
+def test_activation_split_is_exact_and_bounded_on_the_device():
+    """The three-term activation split of DMX_GEMM_BF16X3 as the kernels compute it (igemm_common.h split3_pk, run on the
+    GPU through dmx_debug_split_activations): a1 + a2 + a3 == x exactly for every finite fp32 tried (random bit patterns
+    over the whole exponent range, fp32 denormals, powers of two +- 1 ulp, the fp16 grid, +-0, FLT_MAX); the terms are
+    ordered, |a2| <= 2^-8 |x| and |a3| <= 2^-16 |x| up to the binade (what bounds the dropped a3 w2 product by
+    2^-24 |a w|); +-inf keeps a1 = +-inf and NaN stays NaN - a non-finite operand can only give a non-finite product."""
+    from demucs_cpp_amd import binding as dmx
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2**32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.finfo(np.float32).max, -np.finfo(np.float32).max, np.finfo(np.float32).tiny,
+                         1e-45, -1e-45, 1.17549421e-38, 3.0e-39, 65504.0, 6.1e-5, 5.96e-8], np.float32)
+    p2 = np.concatenate([np.nextafter(np.float32(2.0) ** e, np.float32(s)) for e in range(-126, 127, 7) for s in (0, 4e38)] +
+                        [np.float32(2.0) ** np.arange(-126, 128, dtype=np.float32)]).astype(np.float32).ravel()
+    f16 = np.arange(0, 1 << 16, dtype=np.uint16).view(np.float16).astype(np.float32)
+    f16 = f16[np.isfinite(f16)]
+    x = np.concatenate([x, specials, p2, f16]).astype(np.float32)
+    planes = dmx.split_activations(x)
+    a = (planes.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.array_equal(a[0] + a[1] + a[2], x.astype(np.float64))  # exact (fp64 holds the three-term sum exactly)
+    ax = np.abs(x.astype(np.float64))
+    norm = ax >= 2.0 ** -100  # (below, remainders reach the denormal range of bf16 = of fp32; still exact, bounds in ulps differ)
+    assert (np.abs(a[1])[norm] <= 2.0 ** -8 * ax[norm] * 1.0000001).all()
+    assert (np.abs(a[2])[norm] <= 2.0 ** -16 * ax[norm] * 1.0000001).all()
+    inf = dmx.split_activations(np.array([np.inf, -np.inf, np.nan, 1.0], np.float32))
+    t = (inf.astype(np.uint32) << 16).view(np.float32)
+    assert t[0, 0] == np.inf and t[0, 1] == -np.inf and np.isnan(t[0, 2])
+    assert np.isnan(t[1, :3]).all() or (t[1, :2] == 0).all()  # the remainder of a non-finite value is NaN
+    assert (t[:, 3] == np.array([1.0, 0.0, 0.0], np.float32)).all()
+
+
+def test_non_finite_and_denormal_inputs_behave_like_the_fp32_path(tmp_models):
+    """Both GEMM modes on the same inputs: a NaN / inf sample poisons the stems it reaches in both (never a silently finite
+    result from a non-finite operand); an all-denormal mix and an exactly zero one stay finite and agree."""
+    from demucs_cpp_amd import binding as dmx
+    seg = 6000
+    m = dmx.Model(tmp_models[4])
+    ctxs = [dmx.Context(m, seg, 1, gemm=g) for g in (dmx.GEMM_F32, dmx.GEMM_BF16X3)]
+    base = (0.1 * np.random.default_rng(3).standard_normal((2, seg))).astype(np.float32)
+    for bad in (np.nan, np.inf):
+        mix = base.copy()
+        mix[0, 3000] = bad
+        for c in ctxs:
+            assert not np.isfinite(c.segment(mix)).all()
+    tiny = np.full((2, seg), 1e-41, np.float32)
+    tiny[1, ::2] *= -1
+    outs = [c.segment(tiny) for c in ctxs]
+    assert all(np.isfinite(o).all() for o in outs)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-4 * max(np.abs(outs[0]).max(), 1e-30)
+    for c in ctxs:
+        c.close()
+    m.close()

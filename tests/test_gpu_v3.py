@@ -19,13 +19,6 @@ SEG_FULL = 343980
 
 
 @pytest.fixture(scope="module")
-def dmx():
-    from demucs_cpp_amd import binding
-    assert binding.device_count() >= 1, "no HIP device: the product has no CPU fallback"
-    return binding
-
-
-@pytest.fixture(scope="module")
 def oracle_threads():
     orc.lib().orc_set_num_threads(min(32, os.cpu_count() or 1))
 
