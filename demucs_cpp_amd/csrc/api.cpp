@@ -252,8 +252,17 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     opts.gemm = c->gemm;
     build_plan(c->m->pm, c->seg, batch, *p, opts);
     for (Op &op : p->ops)
+    {
         if (op.kind == OP_IGEMM)
             op.g.split = split_ok(c, op.g) ? 1 : 0;
+        if (op.kind == OP_ATTENTION)
+        {
+            AttnArgs t{};
+            t.hs = op.at.hs;
+            static const bool attSplitOff = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0; // A/B: fp32 attention in split contexts
+            op.at.split = c->gemm == DMX_GEMM_BF16X3 && !attSplitOff && launch_attention_split(t, nullptr, true) == 0 ? 1 : 0;
+        }
+    }
     Plan *raw = p.get();
     c->plans[batch] = std::move(p);
     return raw;
@@ -656,9 +665,10 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_ATTENTION:
     {
         const Attention &t = op.at;
-        launch_attention(AttnArgs{a(t.q), a(t.k), a(t.v), a(t.o), t.ldq, t.ldk, t.ldv, t.ldo, t.qBatch, t.kBatch, t.vBatch,
-                                  t.oBatch, t.B, t.Tq, t.Tk, t.H, t.hs, t.scale},
-                         s);
+        const AttnArgs k{a(t.q), a(t.k), a(t.v), a(t.o), t.ldq, t.ldk, t.ldv, t.ldo, t.qBatch, t.kBatch, t.vBatch,
+                         t.oBatch, t.B, t.Tq, t.Tk, t.H, t.hs, t.scale};
+        if (!(t.split && launch_attention_split(k, s) == 0))
+            launch_attention(k, s);
         break;
     }
     case OP_ISTFT:
@@ -1192,7 +1202,7 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
     case OP_ATTENTION:
     {
         const Attention &t = op.at;
-        kernel = "attention";
+        kernel = t.split ? "attention_split" : "attention";
         flops = 4.0 * t.B * t.H * (double)t.Tq * t.Tk * t.hs;
         bytes = 4.0 * t.B * t.H * t.hs * (2.0 * t.Tq + 2.0 * t.Tk);
         break;

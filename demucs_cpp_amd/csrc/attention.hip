@@ -25,7 +25,7 @@
 //            16 consecutive dims are conflict-free under any permutation inside aligned groups of 4.
 // Online softmax: row maxima / sums cross the 4 lanes of a query with v_permlane16_swap / v_permlane32_swap (VALU)
 // instead of two LDS round trips (ds_bpermute) in the middle of the dependency chain.
-#include "kernels.h"
+#include "attention_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -43,31 +43,7 @@
 namespace dmx
 {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float a4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
-__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); } // v_max3_f32
-static constexpr float kDeferLog2 = 16.0f; // exp2-domain threshold of the deferred running maximum
-
-// Reductions over the 4 lanes {l, l^16, l^32, l^48} that hold one query's keys, on the VALU:
-// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
-// v_permlane32_swap the upper half of the first with the lower half of the second; applied to two copies of x
-// they leave (x[row^1] | x) resp. (x[half^1] | x) side by side.
-__device__ __forceinline__ float quad_lanes_max(float x)
-{
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float quad_lanes_sum(float x)
-{
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // global -> LDS load of 16 bytes per lane (global_load_lds_dwordx4): lane l writes lds_base + 16 l; lds_base is
 // wave-uniform (M0). The builtin exists in the device pass only. (Semantics: tools/micro/lds_dma.hip.)
@@ -103,24 +79,9 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, h4 = lane >> 4;
-    // workgroup -> (query tile, batch*head). Workgroup w runs on XCD w % 8: with the XCD-aware map every
-    // query tile of one (batch, head) lands on the same XCD, so its K and V (2 x Tk x d_h x 4 B, 1.4 MB)
-    // are fetched once and re-read from that XCD's L2 instead of once per XCD.
     unsigned qt, bh;
-    if (p.xcdMap)
-    {
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const unsigned g = j / p.nQt;
-        qt = j - g * p.nQt;
-        bh = g * 8u + xcd;
-        if (bh >= (unsigned)(p.B * p.H))
-            return;
-    }
-    else
-    {
-        bh = blockIdx.x / p.nQt;
-        qt = blockIdx.x - bh * p.nQt;
-    }
+    if (!att_tile_of_block(p, qt, bh)) // XCD-aware workgroup -> (query tile, batch * head) map (attention_common.h)
+        return;
     const int b = (int)(bh / (unsigned)p.H), head = (int)(bh - (unsigned)b * (unsigned)p.H);
     const int q0 = (int)qt * (64 * QF) + wave * (16 * QF);
     const float *Q = p.q + (i64)b * p.qB + head * HS;
@@ -130,7 +91,7 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
     // Q fragments: lane holds Q[q0 + 16 f + l15][16kk + 4h4 .. +3]
     // pre-multiplied by scale * log2(e): the scores leave the MFMAs in the exp2 domain (softmax is
     // invariant; for d_h = 64 the scale 1/8 is exact, so only the log2(e) factor adds one rounding)
-    const float qs = p.scale * 1.44269504088896340736f;
+    const float qs = p.scale * kLog2e;
     float4 qf[QF][DF];
 #pragma unroll
     for (int f = 0; f < QF; ++f)
@@ -158,7 +119,7 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 g += ((float)(n + 1) * 0.5f) * (0.5f / (1.0f + __expf(-dl[n])));
-            gq[f] = g * 1.44269504088896340736f;
+            gq[f] = g * kLog2e;
         }
     }
 
@@ -278,84 +239,19 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
                         sT[f][kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c(kv[kf], c), a4c(qf[f][kk], c), sT[f][kf], 0, 0, 0);
         }
     };
-    // online softmax of tile t for query (f, l15); lane holds keys 16kf + 4h4 + r. MASK: the (only) tile of a Tk
-    // that is not a multiple of 64
+    // online softmax of tile t for query (f, l15); lane holds keys 16kf + 4h4 + r (attention_common.h). MASK: the (only)
+    // tile of a Tk that is not a multiple of 64
     float mcur[QF]; // maximum the current tile of fragment f is exponentiated against (set by softmax_pre)
     auto softmax_pre = [&](int t, int f, f32x4 (*sT)[4], auto maskTag) {
         constexpr bool MASK = decltype(maskTag)::value;
         if (DMX_ABL_ATT_NOSM)
             return;
-        if constexpr (LOC)
-        {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                {
-                    const int key = t * KT + 16 * kf + 4 * h4 + r;
-                    const float dist = fabsf((float)(key - qrow[f]));
-                    sT[f][kf][r] = key == qrow[f] ? -100.0f * 1.44269504088896340736f : sT[f][kf][r] - dist * gq[f];
-                }
-        }
-        if constexpr (MASK)
-        {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (t * KT + 16 * kf + 4 * h4 + r >= p.Tk)
-                        sT[f][kf][r] = -INFINITY;
-        }
-        float tmax = max3f(sT[f][0][0], sT[f][0][1], sT[f][0][2]);
-        tmax = max3f(tmax, sT[f][0][3], sT[f][1][0]);
-        float tmx2 = max3f(sT[f][1][1], sT[f][1][2], sT[f][1][3]);
-        tmx2 = max3f(tmx2, sT[f][2][0], sT[f][2][1]);
-        float tmx3 = max3f(sT[f][2][2], sT[f][2][3], sT[f][3][0]);
-        tmx3 = max3f(tmx3, sT[f][3][1], sT[f][3][2]);
-        tmax = max3f(tmax, tmx2, fmaxf(tmx3, sT[f][3][3]));
-        tmax = quad_lanes_max(tmax);
-        float mnew = mrun[f];
-        // The running maximum is raised only when some score of this 16-query fragment exceeds it by more than
-        // 2^16 (wave-uniform per fragment, hence the same decision in the 64- and the 128-query workgroup
-        // shape; always taken on the first tile, mrun = -inf). Otherwise the tile is exponentiated against the
-        // old maximum - in fp32 a common factor <= 2^16 on P and on the row sum costs no accuracy - and the
-        // rescale of O (one exp + 17 multiplies per fragment) is skipped.
-        // (Measured alternative, kept out: the rescale without a branch, alpha = 1 when the maximum stays, makes the
-        // pipelined step ONE basic block so that the scheduler can spread the next tile's score MFMAs over all the
-        // exponentials - but the always-executed rescale and the longer live ranges cost more than the overlap
-        // gains: 118.3 vs 123.8 TFLOP/s for the 64-query shape, spills in the loop for the 128-query shape.)
-        if (__builtin_amdgcn_ballot_w64(tmax > mnew + kDeferLog2) != 0ull)
-        {
-            mnew = fmaxf(mnew, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew); // first tile: exp2(-inf) = 0
-            lrun[f] *= alpha;
-            mrun[f] = mnew;
-#pragma unroll
-            for (int d = 0; d < DF; ++d)
-            {
-                o[f][d][0] *= alpha;
-                o[f][d][1] *= alpha;
-                o[f][d][2] *= alpha;
-                o[f][d][3] *= alpha;
-            }
-        }
-        mcur[f] = mnew;
+        att_softmax_pre<DF, MASK, LOC>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, qrow[f], gq[f]);
     };
     auto softmax_post = [&](int f, f32x4 (*sT)[4]) {
         if (DMX_ABL_ATT_NOSM)
             return;
-        const float mnew = mcur[f];
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                const float pv = __builtin_amdgcn_exp2f(sT[f][kf][r] - mnew); // bare v_exp_f32: underflow to 0 is the right answer
-                sT[f][kf][r] = pv;
-                ps[kf] += pv;
-            }
-        lrun[f] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        att_softmax_post(sT[f], lrun[f], mcur[f]);
     };
     // O_f^T += V^T P_f^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c] = one float4 of the V image
     auto pvprod = [&](int buf, f32x4 (*sT)[4]) {
@@ -494,19 +390,7 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
     static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
     AttnArgs a = a0;
     a.xcdMap = xcdMap;
-    // 32 queries per wave (128 per workgroup) when that still leaves >= 2 rounds of workgroups per CU;
-    // the key-tile order, hence every rounding, is the same for both shapes
-    // (rounds of the 512 resident workgroups) x (relative duration of one workgroup): the 64-query
-    // shape does ~0.6x the work of the 128-query one per workgroup (K/V LDS reads amortised over half the
-    // queries); e.g. Tq = 1344 at batch 12 is 1056 big workgroups = 2.06 rounds -> 3, or 2016 small = 3.94 -> 4 x 0.6
-    const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B, wg64 = (long)((a.Tq + 63) / 64) * a.H * a.B;
-    const double costBig = (double)((wg128 + 511) / 512), costSmall = 0.6 * (double)((wg64 + 511) / 512);
-    static const int forceSmall = getenv("DMX_ATT_SMALL") ? atoi(getenv("DMX_ATT_SMALL")) : 0; // experiment: 64-query workgroups everywhere
-    static const int forceBig = getenv("DMX_ATT_BIG") ? atoi(getenv("DMX_ATT_BIG")) : 0; // experiment: 128-query workgroups everywhere
-    // Below two full rounds of 128-query workgroups the launch is latency-bound, not matrix-bound, and the 64-query
-    // shape (twice the waves for the same work) wins whatever the round count says: measured at 1 / 2 / 4 segments
-    // 1.12 / 1.78 / 3.17 ms (64) vs 1.39 / 2.05 / 3.32 ms (128) for the ten attention launches of a plan run.
-    const bool big = forceBig || (!forceSmall && wg128 >= 1024 && costBig <= costSmall);
+    const bool big = att_use_big_shape(a); // 128- or 64-query workgroups (attention_common.h)
     if (a.hs != 64 && a.hs != 48)
         abort();
     a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);

@@ -139,6 +139,9 @@ struct AttnArgs
 };
 
 void launch_attention(const AttnArgs &a, hipStream_t s);
+// GEMM_BF16X3 contexts: the same attention with both products on the bf16 matrix pipe through exact three-term operand
+// splits (attention_split.hip); -1 = no kernel for this head dim. dry = availability check only
+int launch_attention_split(const AttnArgs &a, hipStream_t s, bool dry = false);
 // Demucs v3 LocalState (src/layers.cpp:533-721) on the same flash kernel: scores + decay penalty, diagonal = -100;
 // head dims 48 / 96. Returns -1 for other shapes.
 int launch_attention_local(const AttnArgs &a, hipStream_t s);

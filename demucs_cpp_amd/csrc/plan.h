@@ -163,6 +163,7 @@ struct Attention
     i64 qBatch, kBatch, vBatch, oBatch; // batch strides (elements)
     int B, Tq, Tk, H, hs;
     float scale; // 1/sqrt(hs)
+    int split;   // GEMM_BF16X3 contexts (api.cpp): run on the exact-split bf16 kernel (attention_split.hip)
 };
 
 struct Istft
