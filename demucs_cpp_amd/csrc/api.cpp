@@ -7,6 +7,7 @@
 // No CPU fallback exists: without a usable HIP device every compute entry point fails.
 #include "api_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -135,21 +136,18 @@ extern "C" int dmx_debug_split_activations(int device, const float *x, int64_t n
 static bool split_ok(const dmx_ctx *c, const IGemm &g)
 {
     const dmx_model *m = c->m;
-    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb || m->pm.blob.size() != m->blobFloats)
+    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb)
         return false;
     GemmArgs k{};
     k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
     k.Wb1 = k.Wb2 = m->dWb;
     if (launch_igemm_split(g.cfg, k, nullptr, true) != 0)
         return false;
-    const float *w = m->pm.blob.data() + g.w_w;
-    for (i64 i = 0; i < (i64)g.Np * g.Kp; ++i)
-    {
-        unsigned short w1, w2;
-        if (!dmx_split_weight(w[i], w1, w2))
-            return false;
-    }
-    return true;
+    // any inexact element inside [w_w, w_w + Np * Kp)? (the list is computed when the weights are uploaded: the same for the
+    // model and every replica of it, so all devices of an engine take the same decision)
+    const i64 lo = g.w_w, hi = g.w_w + (i64)g.Np * g.Kp;
+    auto it = std::lower_bound(m->inexactW.begin(), m->inexactW.end(), lo);
+    return it == m->inexactW.end() || *it >= hi;
 }
 
 int dmx_model_upload(dmx_model *m, const float *blob)
@@ -172,8 +170,10 @@ int dmx_model_upload(dmx_model *m, const float *blob)
         // Exact for fp16-representable values (11 significand bits <= 8 + 8, fp16 subnormals included: bf16 has the fp32
         // exponent range); whether an op's weights ARE exact is checked per op when the plan is built (split_ok).
         std::vector<unsigned short> planes(2 * m->blobFloats + 1024, 0);
+        m->inexactW.clear();
         for (size_t i = 0; i < m->blobFloats; ++i)
-            (void)dmx_split_weight(blob[i], planes[i], planes[m->blobFloats + 512 + i]);
+            if (!dmx_split_weight(blob[i], planes[i], planes[m->blobFloats + 512 + i]))
+                m->inexactW.push_back((i64)i);
         HIPCHK(hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short)));
         HIPCHK(hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }

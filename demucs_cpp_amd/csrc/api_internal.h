@@ -38,6 +38,8 @@ struct dmx_model
     float *dW = nullptr;
     unsigned short *dWb = nullptr; // two bf16 planes of the blob (GEMM_BF16X3 contexts): w = w1 + w2 by round-to-nearest splits,
                                    // plane 2 starts at element blobFloats + 512
+    std::vector<dmx::i64> inexactW; // blob elements that are NOT the exact sum of their two planes (derived tensors), ascending;
+                                    // filled at upload, so replicas on other devices (dmx_model_clone) agree with the original
     int device = 0;
 };
 // uploads `blob` (blobFloats floats) as the weights of `m` on m->device

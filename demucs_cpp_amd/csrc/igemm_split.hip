@@ -23,6 +23,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Ablation mask for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_SPLIT_ABL=<bits>"`): removes one ingredient of the K loop
+// so that its cost can be read off a per-op profile. Results of such a build are WRONG by construction; 0 in the product.
+//   1: no operand split (the three planes get the same truncated bits)   2: no ds_write of A   4: no ds_write of B
+//   8: no barrier in the loop   16: no global loads in the loop
+#ifndef DMX_SPLIT_ABL
+#define DMX_SPLIT_ABL 0
+#endif
+
 namespace dmx
 {
 
@@ -73,8 +81,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < BR; ++i)
         bPtr[i] = w.bRowOk[i] ? (bPlane ? p.Wb2 : p.Wb1) + (w.bRow[i] - p.Wt) + bOct * 8 : reinterpret_cast<const unsigned short *>(p.zero);
+    bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
+        if ((DMX_SPLIT_ABL & 16) && inLoop)
+            return;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
             aRegS[SET][i] = *reinterpret_cast<const f32x4 *>(w.addrA[i]);
@@ -103,8 +114,22 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             const f32x4 v = w.transform(aRegS[SET][i], i, (maskHeldS[SET] >> i) & 1u, gWS[SET], gBS[SET]);
             // exact three-way split (igemm_common.h): element k = 4 slane + c sits at bits [16 (k & 7), +16) of its octet
             unsigned h1[2], h2[2], h3[2];
-            split3_pk(v[0], v[1], h1[0], h2[0], h3[0]);
-            split3_pk(v[2], v[3], h1[1], h2[1], h3[1]);
+            if (DMX_SPLIT_ABL & 1)
+            {
+                h1[0] = h2[0] = h3[0] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+                h1[1] = h2[1] = h3[1] = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
+            }
+            else
+            {
+                split3_pk(v[0], v[1], h1[0], h2[0], h3[0]);
+                split3_pk(v[2], v[3], h1[1], h2[1], h3[1]);
+            }
+            if (DMX_SPLIT_ABL & 2)
+            {
+                if (h1[0] == 0x12345678u && h2[1] == 0x9abcdef0u && h3[0] == 1u) // keeps the values alive without the stores
+                    Ap[0][0][0] = u32x4{h1[0], h1[1], h2[0], h3[1]};
+                continue;
+            }
             const int row = srow + i * RP;
             const int slot = (slane >> 1) ^ swz(row);
             *(reinterpret_cast<u32x2 *>(&Ap[0][row][slot]) + (slane & 1)) = u32x2{h1[0], h1[1]};
@@ -116,6 +141,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
         {
             if (i < b0 || i >= b1e)
                 continue;
+            if (DMX_SPLIT_ABL & 4)
+            {
+                if (bRegS[SET][i][0] == 0x12345678u && bRegS[SET][i][3] == 0x9abcdef0u)
+                    Bp[0][0][0] = bRegS[SET][i];
+                continue;
+            }
             const int row = srow + i * RP;
             Bp[bPlane][row][bOct ^ swz(row)] = bRegS[SET][i];
         }
@@ -196,8 +227,10 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             a1 = n1, a2 = n2, a3 = n3;
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!(DMX_SPLIT_ABL & 8))
+            __syncthreads();
     };
+    inLoop = true;
     for (int kt = 0; kt < nk; kt += 2)
     {
         iteration(set0);

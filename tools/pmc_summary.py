@@ -23,7 +23,7 @@ def kernel_class(name: str) -> str:
     if "igemm_lin256_kernel" in name:
         return "igemm_lin256x128"
     for key, cls in (("lstm_kernel", "lstm"), ("local_attn_kernel", "local_attn"), ("group_stats", "group_stats"), ("gn_act_kernel", "gn_act"),
-                     ("dgemm_k1_ring_kernel", "dgemm_k1_ring"), ("dgemm_kernel", "dgemm_direct"), ("attention_kernel", "attention"), ("track_stats", "track_stats"),
+                     ("dgemm_k1_ring_kernel", "dgemm_k1_ring"), ("dgemm_kernel", "dgemm_direct"), ("attention_split_kernel", "attention_split"), ("attention_kernel", "attention"), ("track_stats", "track_stats"),
                      ("track_gather", "track_gather"), ("track_ola", "track_ola"), ("istft_ola", "istft_ola"), ("istft", "istft"), ("stft", "stft"),
                      ("stats_", "stats_reduce"), ("layernorm", "layernorm"), ("gn_apply", "gn_apply"), ("ola_kernel", "ola")):
         if key in name:
