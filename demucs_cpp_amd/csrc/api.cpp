@@ -136,7 +136,8 @@ extern "C" int dmx_debug_split_activations(int device, const float *x, int64_t n
 static bool split_ok(const dmx_ctx *c, const IGemm &g)
 {
     const dmx_model *m = c->m;
-    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb)
+    static const bool igemmSplitOff = getenv("DMX_IGEMM_SPLIT") && atoi(getenv("DMX_IGEMM_SPLIT")) == 0; // A/B: fp32 GEMMs in split contexts
+    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb || igemmSplitOff)
         return false;
     GemmArgs k{};
     k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
@@ -268,6 +269,180 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     return raw;
 }
 
+// --------------------------------------------------------------------------- device lanes
+// The cooperative LSTM kernel (v3.hip) spins on partner workgroups. Within ONE launch in-order dispatch makes that safe; a
+// launch is dealt to the XCDs in blocks of 8 recurrences (8 x 12 / 24 workgroups), so the unit that must be resident
+// together is 96 / 192 workgroups and three concurrent launches at H = 384 can exceed the 512 resident workgroups of the
+// device (the bounded spin then raises the status word: an error, never a hang). Launches on one device therefore form a
+// lane: each waits for the previous one's completion event, whatever stream or context of this process issued it. Graph
+// captures (batches below 8: at most 48 spinning workgroups per launch, i.e. ten concurrently replaying contexts fit)
+// stay outside, a capture cannot wait on a foreign event. Lanes are created on demand, one per visible device, and live
+// until the process ends (their events are not destroyed from a static destructor: the HIP runtime may be gone by then).
+//
+// PLAN lane (round 4). Contexts of DMX_GEMM_BF16X3 must not run concurrently with ANOTHER context's work on the same GPU:
+// with two contexts on one device (logical devices of an engine, the threads of the C++ shim), single 16-bin blocks of
+// single STFT / ISTFT frames of one context came out wrong while the other context's bf16 MFMA kernels were resident -
+// never with fp32 MFMA kernels, never with the bf16 kernels' MFMAs compiled out (their loads, splits, LDS traffic and
+// barriers alone do not do it), not reproduced by an LDS-privacy micro-benchmark (tools/micro/lds_overlap.hip) and not by
+// one context alone, whose FFT kernels never overlap its split kernels (gpurun_out diagnostics tools/gpu_diag_split*.py;
+// DESIGN.md section 7.5). Cause not established (it looks like a platform problem); the library's answer is ordering: while a
+// bf16x3 context exists on a device, every plan run on that device waits for the previous one's completion event, whatever
+// context or stream issued it, and - when several PROCESSES share the GPU and one of them holds a bf16x3 context - plan
+// runs take turns through the process-shared mutex. One context per GPU (the deployment case, and one process per GPU in
+// bench.py) never waits.
+struct SharedLane // one per GPU in POSIX shared memory, keyed by the PCI bus id
+{
+    std::atomic<int> ready;
+    std::atomic<int> nprocs;
+    std::atomic<int> nSplit; // bf16x3 contexts alive on this GPU, all processes
+    pthread_mutex_t mu;
+};
+struct LstmLane
+{
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    bool recorded = false;
+    SharedLane *shared = nullptr;
+    // plan lane
+    std::mutex planMu;
+    hipEvent_t planEv = nullptr;
+    bool planRecorded = false;
+    std::atomic<int> nSplit{0}; // bf16x3 contexts of this process on this device
+};
+static thread_local bool t_sharedHeld = false; // this thread holds the process-shared mutex (plan level): the LSTM level must not take it again
+static std::mutex g_lanesMu;
+static std::vector<std::unique_ptr<LstmLane>> g_lanes;
+static std::vector<SharedLane *> g_sharedRegistered;
+
+static SharedLane *open_shared_lane(int device)
+{
+    if (const char *e = getenv("DMX_LSTM_SHARED_LANE"))
+        if (atoi(e) == 0)
+            return nullptr;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess)
+        return nullptr;
+    std::string name = "/dmx_lstm_lane_";
+    for (const char *q = bus; *q; ++q)
+        name += (isalnum((unsigned char)*q) ? *q : '_');
+    bool creator = true;
+    int fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0666);
+    if (fd < 0)
+    {
+        creator = false;
+        fd = shm_open(name.c_str(), O_RDWR, 0666);
+    }
+    if (fd < 0)
+        return nullptr;
+    if (creator && ftruncate(fd, sizeof(SharedLane)) != 0)
+    {
+        close(fd);
+        shm_unlink(name.c_str());
+        return nullptr;
+    }
+    void *mem = MAP_FAILED;
+    for (int tries = 0; tries < 200 && mem == MAP_FAILED; ++tries) // a second opener may arrive before the creator's ftruncate
+    {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SharedLane))
+            mem = mmap(nullptr, sizeof(SharedLane), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        else
+            usleep(1000);
+    }
+    close(fd);
+    if (mem == MAP_FAILED)
+        return nullptr;
+    SharedLane *sl = static_cast<SharedLane *>(mem);
+    if (creator)
+    {
+        pthread_mutexattr_t at;
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+        pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST);
+        pthread_mutex_init(&sl->mu, &at);
+        pthread_mutexattr_destroy(&at);
+        sl->nprocs.store(0);
+        sl->nSplit.store(0);
+        sl->ready.store(1, std::memory_order_release);
+    }
+    else
+        for (int tries = 0; tries < 2000 && sl->ready.load(std::memory_order_acquire) != 1; ++tries)
+            usleep(1000);
+    if (sl->ready.load(std::memory_order_acquire) != 1)
+        return nullptr;
+    sl->nprocs.fetch_add(1);
+    g_sharedRegistered.push_back(sl);
+    static bool hooked = false;
+    if (!hooked)
+    {
+        hooked = true;
+        atexit([] {
+            for (SharedLane *l : g_sharedRegistered)
+                l->nprocs.fetch_sub(1);
+        });
+    }
+    return sl;
+}
+
+static LstmLane *lstm_lane(int device)
+{
+    std::lock_guard<std::mutex> lk(g_lanesMu);
+    if (g_lanes.empty())
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            return nullptr;
+        g_lanes.resize((size_t)n);
+    }
+    if (device < 0 || device >= (int)g_lanes.size())
+        return nullptr;
+    if (!g_lanes[(size_t)device])
+    {
+        g_lanes[(size_t)device] = std::make_unique<LstmLane>();
+        g_lanes[(size_t)device]->shared = open_shared_lane(device);
+    }
+    return g_lanes[(size_t)device].get();
+}
+
+static void plan_lane_leave(int device)
+{
+    if (LstmLane *lane = lstm_lane(device))
+    {
+        lane->nSplit.fetch_sub(1);
+        if (lane->shared)
+            lane->shared->nSplit.fetch_sub(1);
+    }
+}
+
+// holds the process-shared mutex of a lane while another process is registered on the same GPU
+struct SharedLaneGuard
+{
+    SharedLane *sl = nullptr;
+    explicit SharedLaneGuard(SharedLane *l, bool want = true)
+    {
+        if (l && want && !t_sharedHeld && l->nprocs.load() > 1)
+        {
+            const int rc = pthread_mutex_lock(&l->mu);
+            if (rc == EOWNERDEAD)
+                pthread_mutex_consistent(&l->mu);
+            if (rc == 0 || rc == EOWNERDEAD)
+            {
+                sl = l;
+                t_sharedHeld = true;
+            }
+        }
+    }
+    bool held() const { return sl != nullptr; }
+    ~SharedLaneGuard()
+    {
+        if (sl)
+        {
+            t_sharedHeld = false;
+            pthread_mutex_unlock(&sl->mu);
+        }
+    }
+};
+
 static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int max_batch, int gemm)
 {
     c->m = m;
@@ -304,6 +479,14 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&c->hStatus, sizeof(unsigned), hipHostMallocDefault));
     *c->hStatus = 0;
+    if (gemm == DMX_GEMM_BF16X3)
+        if (LstmLane *lane = lstm_lane(m->device)) // from now on the plan runs of this device are ordered (device lanes)
+        {
+            lane->nSplit.fetch_add(1);
+            if (lane->shared)
+                lane->shared->nSplit.fetch_add(1);
+            c->inPlanLane = true;
+        }
     return DMX_OK;
 }
 
@@ -335,6 +518,7 @@ extern "C" int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, 
 // mutex; a launch only enqueues (tens of microseconds), so the device threads lose no overlap.
 static std::mutex g_graphMutex;
 
+static void plan_lane_leave(int device);
 dmx_ctx::~dmx_ctx()
 {
     if (!m)
@@ -342,6 +526,8 @@ dmx_ctx::~dmx_ctx()
     (void)hipSetDevice(m->device);
     if (stream)
         (void)hipStreamSynchronize(stream);
+    if (inPlanLane)
+        plan_lane_leave(m->device);
     {
         std::lock_guard<std::mutex> graphLock(g_graphMutex);
         for (auto &kv : graphs)
@@ -449,144 +635,6 @@ extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     return DMX_OK;
 }
-
-// --------------------------------------------------------------------------- LSTM lane
-// The cooperative LSTM kernel (v3.hip) spins on partner workgroups. Within ONE launch in-order dispatch makes that safe; a
-// launch is dealt to the XCDs in blocks of 8 recurrences (8 x 12 / 24 workgroups), so the unit that must be resident
-// together is 96 / 192 workgroups and three concurrent launches at H = 384 can exceed the 512 resident workgroups of the
-// device (the bounded spin then raises the status word: an error, never a hang). Launches on one device therefore form a
-// lane: each waits for the previous one's completion event, whatever stream or context of this process issued it. Graph
-// captures (batches below 8: at most 48 spinning workgroups per launch, i.e. ten concurrently replaying contexts fit)
-// stay outside, a capture cannot wait on a foreign event. Lanes are created on demand, one per visible device, and live
-// until the process ends (their events are not destroyed from a static destructor: the HIP runtime may be gone by then).
-struct SharedLane // one per GPU in POSIX shared memory, keyed by the PCI bus id
-{
-    std::atomic<int> ready;
-    std::atomic<int> nprocs;
-    pthread_mutex_t mu;
-};
-struct LstmLane
-{
-    std::mutex mu;
-    hipEvent_t ev = nullptr;
-    bool recorded = false;
-    SharedLane *shared = nullptr;
-};
-static std::mutex g_lanesMu;
-static std::vector<std::unique_ptr<LstmLane>> g_lanes;
-static std::vector<SharedLane *> g_sharedRegistered;
-
-static SharedLane *open_shared_lane(int device)
-{
-    if (const char *e = getenv("DMX_LSTM_SHARED_LANE"))
-        if (atoi(e) == 0)
-            return nullptr;
-    char bus[64] = "";
-    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess)
-        return nullptr;
-    std::string name = "/dmx_lstm_lane_";
-    for (const char *q = bus; *q; ++q)
-        name += (isalnum((unsigned char)*q) ? *q : '_');
-    bool creator = true;
-    int fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0666);
-    if (fd < 0)
-    {
-        creator = false;
-        fd = shm_open(name.c_str(), O_RDWR, 0666);
-    }
-    if (fd < 0)
-        return nullptr;
-    if (creator && ftruncate(fd, sizeof(SharedLane)) != 0)
-    {
-        close(fd);
-        shm_unlink(name.c_str());
-        return nullptr;
-    }
-    void *mem = MAP_FAILED;
-    for (int tries = 0; tries < 200 && mem == MAP_FAILED; ++tries) // a second opener may arrive before the creator's ftruncate
-    {
-        struct stat st;
-        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(SharedLane))
-            mem = mmap(nullptr, sizeof(SharedLane), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        else
-            usleep(1000);
-    }
-    close(fd);
-    if (mem == MAP_FAILED)
-        return nullptr;
-    SharedLane *sl = static_cast<SharedLane *>(mem);
-    if (creator)
-    {
-        pthread_mutexattr_t at;
-        pthread_mutexattr_init(&at);
-        pthread_mutexattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
-        pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST);
-        pthread_mutex_init(&sl->mu, &at);
-        pthread_mutexattr_destroy(&at);
-        sl->nprocs.store(0);
-        sl->ready.store(1, std::memory_order_release);
-    }
-    else
-        for (int tries = 0; tries < 2000 && sl->ready.load(std::memory_order_acquire) != 1; ++tries)
-            usleep(1000);
-    if (sl->ready.load(std::memory_order_acquire) != 1)
-        return nullptr;
-    sl->nprocs.fetch_add(1);
-    g_sharedRegistered.push_back(sl);
-    static bool hooked = false;
-    if (!hooked)
-    {
-        hooked = true;
-        atexit([] {
-            for (SharedLane *l : g_sharedRegistered)
-                l->nprocs.fetch_sub(1);
-        });
-    }
-    return sl;
-}
-
-static LstmLane *lstm_lane(int device)
-{
-    std::lock_guard<std::mutex> lk(g_lanesMu);
-    if (g_lanes.empty())
-    {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-            return nullptr;
-        g_lanes.resize((size_t)n);
-    }
-    if (device < 0 || device >= (int)g_lanes.size())
-        return nullptr;
-    if (!g_lanes[(size_t)device])
-    {
-        g_lanes[(size_t)device] = std::make_unique<LstmLane>();
-        g_lanes[(size_t)device]->shared = open_shared_lane(device);
-    }
-    return g_lanes[(size_t)device].get();
-}
-
-// holds the process-shared mutex of a lane while another process is registered on the same GPU
-struct SharedLaneGuard
-{
-    SharedLane *sl = nullptr;
-    explicit SharedLaneGuard(SharedLane *l)
-    {
-        if (l && l->nprocs.load() > 1)
-        {
-            const int rc = pthread_mutex_lock(&l->mu);
-            if (rc == EOWNERDEAD)
-                pthread_mutex_consistent(&l->mu);
-            if (rc == 0 || rc == EOWNERDEAD)
-                sl = l;
-        }
-    }
-    bool held() const { return sl != nullptr; }
-    ~SharedLaneGuard()
-    {
-        if (sl)
-            pthread_mutex_unlock(&sl->mu);
-    }
-};
 
 // --------------------------------------------------------------------------- executor
 static unsigned long long *g_dbg = nullptr; // set only by dmx_debug_igemm_timing
@@ -875,6 +923,19 @@ static int run_plan(dmx_ctx *c, int batch)
         }
         c->lastKey = key, c->haveLastKey = true;
     }
+    // plan lane (see "device lanes"): ordered behind the previous plan run of this device while a bf16x3 context exists
+    LstmLane *lane = lstm_lane(c->m->device);
+    const bool laneOn = lane && (lane->nSplit.load() > 0 || (lane->shared && lane->shared->nSplit.load() > 0));
+    std::unique_lock<std::mutex> planLock;
+    if (laneOn)
+    {
+        planLock = std::unique_lock<std::mutex>(lane->planMu);
+        if (!lane->planEv)
+            HIPCHK(hipEventCreateWithFlags(&lane->planEv, hipEventDisableTiming));
+        if (lane->planRecorded)
+            HIPCHK(hipStreamWaitEvent(c->stream, lane->planEv, 0));
+    }
+    SharedLaneGuard shared(lane ? lane->shared : nullptr, laneOn);
     if (exec)
     {
         std::lock_guard<std::mutex> graphLock(g_graphMutex);
@@ -884,6 +945,13 @@ static int run_plan(dmx_ctx *c, int batch)
         DMXCHK(enqueue_plan(c, p, two));
     c->lastBatch = batch;
     HIPCHK(hipGetLastError());
+    if (laneOn)
+    {
+        HIPCHK(hipEventRecord(lane->planEv, c->stream));
+        lane->planRecorded = true;
+    }
+    if (shared.held())
+        HIPCHK(hipStreamSynchronize(c->stream)); // another process may only start its plan run when this one has finished
     return DMX_OK;
 }
 

@@ -50,10 +50,13 @@ __device__ __forceinline__ void load_to_lds_b128(const float *gptr, float4 *lds_
 // ---------------------------------------------------------------------------------------------- exact bf16 splits
 // x = a1 + a2 + a3 with a1 = bf16(x), a2 = bf16(x - a1), a3 = bf16(x - a1 - a2), every conversion round-to-nearest-even
 // (v_cvt_pk_bf16_f32). Each remainder is exact in fp32 and at most half an ulp of the term before it, so
-// |a2| <= 2^-8 |x|, |a3| <= 2^-16 |x| (up to the binade), and the 3 x 8 significand bits plus the two remainder signs
-// cover all 24 bits of a finite fp32: the sum is exact. Non-finite x: a1 = x (inf, or a quiet NaN), a2 = a3 = NaN - any
-// product with it is non-finite, as x itself would make it. Values are returned as PAIRS packed for the MFMA operand
-// registers: low 16 bits = the term of x0, high 16 bits = the term of x1.
+// |a2| <= 2^-8 |x|, |a3| <= 2^-16 |x|, and the 3 x 8 significand bits plus the two remainder signs cover all 24 bits of
+// an fp32: the sum is EXACT for 2^-109 <= |x| <= 0x7f7f7fff (3.3895e38). Outside (measured on the device,
+// tests/test_gpu_parity.py::test_activation_split_is_exact_and_bounded_on_the_device): below 2^-109 a remainder can be a
+// denormal, which the conversion flushes - the sum is then within 2^-125 of x, less than the smallest normal fp32; in the
+// last half-ulp of bf16's range bf16(x) rounds to inf, and for x = +-inf / NaN a1 = x, a2 = a3 = NaN - an operand out of
+// range can only make a product non-finite, as a non-finite operand would in the fp32 kernels. Values are returned as
+// PAIRS packed for the MFMA operand registers: low 16 bits = the term of x0, high 16 bits = the term of x1.
 __device__ __forceinline__ unsigned bf16_pk_rn(float x0, float x1)
 {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));

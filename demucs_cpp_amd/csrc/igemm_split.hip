@@ -2,7 +2,7 @@
 // operand splits, fp32 accumulation (contexts created with DMX_GEMM_BF16X3, include/demucs_hip.h).
 //
 //   activation a (fp32)            = a1 + a2 + a3   three bf16 terms, round-to-nearest splits (igemm_common.h split3_pk):
-//                                                    exact for every finite fp32, |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|
+//                                                    exact for 2^-109 <= |a| < 3.39e38 (igemm_common.h), |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|
 //   weight     w (fp16 in the file) = w1 + w2        two bf16 terms (11 significand bits <= 8 + 8 + sign: exact, |w2| <= 2^-8 |w|;
 //                                                    checked per op on the host, ops whose weights are not exact keep the
 //                                                    fp32 kernel)
@@ -26,9 +26,15 @@
 // Ablation mask for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_SPLIT_ABL=<bits>"`): removes one ingredient of the K loop
 // so that its cost can be read off a per-op profile. Results of such a build are WRONG by construction; 0 in the product.
 //   1: no operand split (the three planes get the same truncated bits)   2: no ds_write of A   4: no ds_write of B
-//   8: no barrier in the loop   16: no global loads in the loop
+//   8: no barrier in the loop   16: no global loads in the loop   32: the kernel returns at once   64: no epilogue (no global stores)   128: no MFMAs   256: no fragment ds_reads
 #ifndef DMX_SPLIT_ABL
 #define DMX_SPLIT_ABL 0
+#endif
+
+#if DMX_SPLIT_ABL & 128
+#define DMX_SPLIT_MFMA(a, b, c, x, y, z) (c)
+#else
+#define DMX_SPLIT_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
 #endif
 
 namespace dmx
@@ -61,6 +67,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     unsigned tileM, tileN;
     if (!tile_of_block(p, tileM, tileN))
         return; // whole workgroup, before any barrier
+    if (DMX_SPLIT_ABL & 32)
+        return;
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
     auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
@@ -207,23 +215,23 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             // smallest terms first; operands swapped (weights as A, activations as B): the accumulator holds C^T
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a3, acc[i][j], 0, 0, 0);
+                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a3, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a2, acc[i][j], 0, 0, 0);
+                acc[i][j] = DMX_SPLIT_MFMA(b2[j], a2, acc[i][j], 0, 0, 0);
             if (i < SH) // tile kt+1: the other register set -> the other image
                 store_tiles(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1, i * AR / SH, (i + 1) * AR / SH, i * BR / SH, (i + 1) * BR / SH);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a1, acc[i][j], 0, 0, 0);
+                acc[i][j] = DMX_SPLIT_MFMA(b2[j], a1, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a2, acc[i][j], 0, 0, 0);
+                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a2, acc[i][j], 0, 0, 0);
             if (i == WMF - 1)
                 w.compute_addrs(); // addresses of tile kt+3
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1, acc[i][j], 0, 0, 0);
+                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a1, acc[i][j], 0, 0, 0);
             a1 = n1, a2 = n2, a3 = n3;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -238,6 +246,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             iteration(set1);
     }
     __syncthreads(); // (rsum aliases the A image)
+    if (DMX_SPLIT_ABL & 64)
+    {
+        if (acc[0][0][0] == 123.456f)
+            p.Y[0] = acc[0][0][1];
+        return;
+    }
 
     igemm_epilogue<WAVES_N, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wm, wn, BM);
 }

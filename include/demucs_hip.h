@@ -80,7 +80,8 @@ extern "C"
      * operation (normalisations, activations, FFTs, reductions) in fp32:
      *   DMX_GEMM_F32    v_mfma_f32_16x16x4_f32: each output is one k-ordered fp32 fmaf chain;
      *   DMX_GEMM_BF16X3 exact operand splits on the bf16 matrix pipe: an activation is the sum of three bf16 terms
-     *                   (a = a1 + a2 + a3, round-to-nearest splits: exact for every finite fp32), a weight - an fp16
+     *                   (a = a1 + a2 + a3, round-to-nearest splits: exact for 2^-109 <= |a| <= 3.3895e38, within 2^-125 below,
+     *                   non-finite above), a weight - an fp16
      *                   number in the file - of two (w = w1 + w2: exact), and a w is accumulated in fp32 from five exact
      *                   partial products; the dropped a3 w2 is <= 2^-24 |a w|. MI355X's bf16 MFMA
      *                   rate is 16x its fp32 MFMA rate. Ops whose weights are not fp16-exact stay on the fp32 kernels.

@@ -107,17 +107,52 @@ def load_dirs(ref_dir: str, est_dir: str):
     return refs, ests
 
 
+REFERENCE_TABLES = {"htdemucs_4s": SDR_SCORES_MD_CPP_4S, "htdemucs_6s": SDR_SCORES_MD_CPP_6S, "htdemucs_ft": SDR_SCORES_MD_CPP_FT,
+                    "hdemucs_mmi": SDR_SCORES_MD_CPP_V3}
+
+
 def main(argv):
-    if len(argv) != 3:
+    """eval_sdr.py <reference dir> <estimate dir>
+    eval_sdr.py --track <reference dir> --estimates <estimate dir> [--reference-table htdemucs_4s|htdemucs_6s|htdemucs_ft|hdemucs_mmi]
+                [--tolerance 0.1]      prints the reference's own C++ score (.github/SDR_scores.md) and the verdict beside each
+                                       target; the exit code is the number of targets outside the tolerance"""
+    ref_dir = est_dir = table = None
+    tol = 0.1
+    args = argv[1:]
+    if len(args) == 2 and not args[0].startswith("--"):
+        ref_dir, est_dir = args
+    else:
+        it = iter(args)
+        for a in it:
+            if a == "--track":
+                ref_dir = next(it, None)
+            elif a == "--estimates":
+                est_dir = next(it, None)
+            elif a == "--reference-table":
+                table = next(it, None)
+            elif a == "--tolerance":
+                tol = float(next(it, "0.1"))
+            else:
+                print(main.__doc__)
+                return 2
+    if not ref_dir or not est_dir or (table is not None and table not in REFERENCE_TABLES):
         print(__doc__)
+        print(main.__doc__)
         return 2
-    refs, ests = load_dirs(argv[1], argv[2])
+    refs, ests = load_dirs(ref_dir, est_dir)
     if not refs:
         print("no matching stems found", file=sys.stderr)
         return 1
+    want = REFERENCE_TABLES.get(table, {})
+    bad = 0
     for name, v in track_sdr(refs, ests).items():
-        print(f"{name:15s} ==> SDR: {v:7.3f}")
-    return 0
+        line = f"{name:15s} ==> SDR: {v:7.3f}"
+        if name in want:
+            ok = abs(v - want[name]) <= tol
+            bad += 0 if ok else 1
+            line += f"   reference C++ {want[name]:7.3f}   delta {v - want[name]:+.3f} dB   {'OK' if ok else 'OUTSIDE +-%.2f dB' % tol}"
+        print(line)
+    return bad
 
 
 if __name__ == "__main__":
