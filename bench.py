@@ -33,8 +33,9 @@ steps.
       168 (model, segment) items per GPU per step, `value` = seconds of track per second for the WHOLE bag
   v3  Demucs v3 hdemucs_mmi
 --gemm f32|bf16x3 selects the GEMM arithmetic of the measured context (include/demucs_hip.h DMX_GEMM_*; default: the
-library default, i.e. environment DMX_GEMM or f32); at N = 1 the OTHER mode is measured on the same workload in the
-same process and reported as config.<mode>_xRT / _ms_per_segment.
+library default = bf16x3, the exact operand-split path, unless the environment says DMX_GEMM=f32); at N = 1 the OTHER
+mode is measured on the same workload in the same process and reported as config.f32_mfma_xRT / _ms_per_segment (or
+config.bf16x3_xRT / ... when the run itself is the fp32 MFMA path).
 
 config also reports, as SCALAR keys, measured in this same run:
   track_4min_host_xRT / track_4min_host_wall_s   (N = 1) the same track end to end with HOST buffers in and out
@@ -175,6 +176,7 @@ def main():
     gemm_names = {"f32": dmx.GEMM_F32, "bf16x3": dmx.GEMM_BF16X3}
     primary = args.gemm or dmx.GEMM_NAMES[dmx.default_gemm()]
     other = "bf16x3" if primary == "f32" else "f32"
+    other_key = "bf16x3" if other == "bf16x3" else "f32_mfma"
     ctx = dmx.Context(models[0], SEG, B, gemm=gemm_names[primary])
 
     # Everything device-side is ordered on ONE torch stream: the library enqueues on it
@@ -533,9 +535,9 @@ def main():
                        "ms_per_segment": round(elapsed / args.steps / (B * M) * 1e3, 3), "outputs_finite": finite,
                        "gemm_path": primary + ": " + arith[primary],
                        # the other GEMM arithmetic on the same workload, measured in this process right after the timed region
-                       f"{other}_xRT": None if other_run is None else other_run["xRT"],
-                       f"{other}_ms_per_segment": None if other_run is None else other_run["ms_per_segment"],
-                       f"{other}_outputs_finite": None if other_run is None else other_run["finite"],
+                       f"{other_key}_xRT": None if other_run is None else other_run["xRT"],
+                       f"{other_key}_ms_per_segment": None if other_run is None else other_run["ms_per_segment"],
+                       f"{other_key}_outputs_finite": None if other_run is None else other_run["finite"],
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        "parallelism": f"segment-sharded x{world}"},

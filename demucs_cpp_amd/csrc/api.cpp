@@ -83,8 +83,10 @@ extern "C" int dmx_default_gemm(void)
     int g = g_defaultGemm.load();
     if (g < 0)
     {
+        // default since round 4: the exact operand-split path (every -m gpu parity test runs in both modes; DESIGN.md
+        // section 7.2); DMX_GEMM=f32 selects the fp32 MFMA kernels
         const char *e = getenv("DMX_GEMM");
-        g = e && !strcmp(e, "bf16x3") ? DMX_GEMM_BF16X3 : DMX_GEMM_F32;
+        g = e && !strcmp(e, "f32") ? DMX_GEMM_F32 : DMX_GEMM_BF16X3;
         g_defaultGemm.store(g);
     }
     return g;
@@ -731,7 +733,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         const Ola &o = op.ola;
         if (o.x >= 0 && c->fuseIstft)
             launch_istft_ola(IstftOlaArgs{a(o.x), a(o.stats), a(o.xt), a(o.statsT), a(o.wss), a(o.window), a(o.twiddle), a(o.out), o.B, o.T,
-                                          o.S, o.seg, o.pad, 0, 0},
+                                          o.S, o.seg, o.pad, 0, 0, a(o.rden)},
                              s);
         else
             launch_ola(OlaArgs{a(o.frames), a(o.xt), a(o.statsT), a(o.wss), a(o.out), o.B, o.T, o.S, o.seg, o.pad}, s);

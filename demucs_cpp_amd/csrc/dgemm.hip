@@ -622,6 +622,35 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
             a.seg0 == 48 ? launch_k1_ring<48>(a, s) : launch_k1_ring<96>(a, s);
         return 0;
     }
+    // DConv k3 of the deep levels (C = 192 / 384: hidden 24 / 48 -> 2C = 384 / 768 packed columns; layers.cpp:204-259): the
+    // weight matrix no longer fits one wave's registers, so the op runs as COLUMN CHUNKS of 192 (12 fragments = 6 GLU pairs
+    // = 96 output channels) through the 12-fragment kernel: every chunk streams all rows once (hidden row in, its 96
+    // channels of the residual in and out) with its 192 x K weights resident, instead of a 128x128 GEMM tile whose single
+    // half-empty K-tile made the op all prologue and epilogue (round 3: 1.7-2.3 TB/s). The chunks touch disjoint columns of
+    // the in-place tensor; arithmetic per output = the direct kernels' (k ascending, remainder k-slots last).
+    if (a.pro == PRO_GN_GELU && a.epi == EPI_GN_GLU_SCALE_RES && a.S1 == 1 && (a.seg0 == 24 || a.seg0 == 48) && a.N > 192 && a.N % 192 == 0)
+    {
+        if (!dry)
+        {
+            // chunk width: 192 columns keep 12 x K weights in registers (268 / 351 VGPRs: one wave per SIMD) and read the hidden
+            // row N / 192 times; 96 columns (6 fragments, ~130 VGPRs: three to four waves per SIMD) read it N / 96 times.
+            // DMX_K3_CHUNK=96|192 for A/B runs; the default is the measured winner
+            static const int chunkEnv = getenv("DMX_K3_CHUNK") ? atoi(getenv("DMX_K3_CHUNK")) : 0;
+            const int cw = chunkEnv == 96 || chunkEnv == 192 ? chunkEnv : 96;
+            for (int n0 = 0; n0 < a.N; n0 += cw)
+            {
+                GemmArgs c = a;
+                c.Wt += (i64)n0 * a.Kp, c.bias += n0, c.epiW += n0, c.epiB += n0, c.scale += n0 / 2;
+                c.Y += n0 / 2, c.res += n0 / 2;
+                c.N = c.Np = cw;
+                if (cw == 192)
+                    a.seg0 == 24 ? launch_d<12, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1>(c, s) : launch_d<12, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s);
+                else
+                    a.seg0 == 24 ? launch_d<6, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s) : launch_d<6, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s);
+            }
+        }
+        return 0;
+    }
     switch (NF * 1000000 + a.S1 * 100000 + a.seg0 * 100 + a.pro * 10 + a.epi)
     {
         // DConv k1: Conv1d(C -> C/8, k3): C = 48, 96 (time branch; the frequency branch takes the ring kernel above)

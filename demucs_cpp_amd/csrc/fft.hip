@@ -297,8 +297,9 @@ void launch_ola(const OlaArgs &a, hipStream_t s)
 // frame f lands on position n = 1024 f + i of the padded signal, i.e. in hop H = f + (j >> 2) at offset
 // tid + 256 (j & 3): always one of THIS thread's 16 accumulators, ring slot H & 3. A hop receives its last
 // contribution from frame H itself, so after frame f has been added slot f & 3 is complete: it is written
-// out (window-sum-square division done per term, crop, + de-normalised time branch: exactly the arithmetic
-// and the summation order of istft_kernel + ola_kernel, bit for bit) and cleared. The ring rotates with f, so
+// out (window-sum-square normalisation per term, crop, + de-normalised time branch: the summation order of
+// istft_kernel + ola_kernel; the two divisions per term of that form - 32 IEEE divisions per thread and frame - are one
+// multiplication by the precomputed (1 / 4096) / (wss + 1e-8), <= 1 ulp per term apart) and cleared. The ring rotates with f, so
 // the step is instantiated for the 4 values of f & 3 (register indices must be compile-time constants).
 // Chunks start 3 frames early (recomputed halo, no output) so that every hop they emit has all 4 addends.
 //
@@ -316,11 +317,11 @@ __device__ __forceinline__ void istft_ola_step(const IstftOlaArgs &p, float2 (&a
             const int i = tid + 256 * j;
             const float2 z = bufA[FSW(i)]; // `bufA` here is the buffer that holds the transformed frame
             const float w = p.window[i];
-            const float den = p.wss[f * 1024 + i] + 1e-8f;
+            const float rd = p.rden[f * 1024 + i]; // (1 / 4096) / (wss + 1e-8), one table entry per position (plan.cpp)
             const float y0 = z.x * w, y1 = z.y * w; // the value istft_kernel stores in `frames`
             float2 &a = acc[(PH + (j >> 2)) & 3][j & 3];
-            a.x += y0 * 1.0f / 4096.0f / den;
-            a.y += y1 * 1.0f / 4096.0f / den;
+            a.x += y0 * rd; // the reference divides, y / 4096 / (wss + 1e-8) per term (dsp.cpp:151-185): <= 1 ulp apart
+            a.y += y1 * rd;
         }
     }
     if (emit)

@@ -75,25 +75,73 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 
     // ---- per-thread staging state: AR rows of A and BR rows of B, all at k-quad `slane` (no swizzle on the global side)
     const int slane = tid % LPR, srow = tid / LPR;
+    // B chunks (16 bytes = one octet of one plane of one weight row) of a thread. An 8-lane ds_write_b128 group must stay
+    // inside ONE plane: rows are 64 B, so the two planes of a row are 8 KB apart = the same banks (the first form of this
+    // kernel let lanes 0-3 write plane 1 and lanes 4-7 plane 2 of one row: every B store two-way conflicted,
+    // SQ_LDS_BANK_CONFLICT = 17 % of the LDS cycles). BN a multiple of 64: chunk i = plane i & 1 of row
+    // 64 (i >> 1) + 2 (tid >> 3) + ((tid >> 2) & 1) - a group writes two whole rows of one plane, 128 contiguous bytes.
+    // Other widths (96) keep the row-per-8-lanes form.
+    constexpr bool BCF = BN % 64 == 0;
+    const int bOct = BCF ? (tid & 3) : (slane & 3);
+    auto bRowOf = [&](int i) { return BCF ? 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1) : srow + i * RP; };
+    auto bPlaneOf = [&](int i) { return BCF ? (i & 1) : (slane >> 2); };
     StageWalk<AR, BR, KT, PRO, LIN> w(p, slane);
-    w.init(rowinfo_of, [&](int i) { return srow + i * RP; }, [&](int i) { return srow + i * RP; }, n0, BN);
+    w.init(rowinfo_of, [&](int i) { return srow + i * RP; }, bRowOf, n0, BN);
 
     // two staging register sets: a tile is requested a whole iteration before it is written to LDS
     f32x4 aRegS[2][AR], gWS[2], gBS[2];
     u32x4 bRegS[2][BR];
     unsigned maskHeldS[2] = {0u, 0u};
     const int nk = (p.Kp + 31) >> 5;
-    // B planes: lanes 0-3 of a row fetch the octets of plane 1, lanes 4-7 those of plane 2
-    const int bPlane = slane >> 2, bOct = slane & 3;
     const unsigned short *bPtr[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i)
-        bPtr[i] = w.bRowOk[i] ? (bPlane ? p.Wb2 : p.Wb1) + (w.bRow[i] - p.Wt) + bOct * 8 : reinterpret_cast<const unsigned short *>(p.zero);
+        bPtr[i] = w.bRowOk[i] ? (bPlaneOf(i) ? p.Wb2 : p.Wb1) + (w.bRow[i] - p.Wt) + bOct * 8 : reinterpret_cast<const unsigned short *>(p.zero);
     bool inLoop = false; // (ablation builds only)
+    // LIN: a row is one contiguous run of K floats, so a staging address is (uniform base) + (32-bit byte offset that
+    // advances by one K-tile): the loads take the scalar-base form (global_load ... v_off, s[base]) - one address register
+    // per lane instead of a 64-bit pointer pair, one 32-bit add per row and tile. Rows beyond M / columns beyond Np read
+    // the last valid row instead of the zero page: their accumulators are never stored (the launcher takes this path
+    // only when every offset fits 32 bits).
+    unsigned aOff[AR], bOff[BR];
+    if constexpr (LIN)
+    {
+        const i64 rowLen = (i64)p.L0 * p.Cin;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+        {
+            const i64 m = min(m0 + srow + i * RP, p.M - 1);
+            const int4 ri = row_info(p, m);
+            aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + slane * 16);
+        }
+        const unsigned planeDelta = (unsigned)(p.Wb2 - p.Wb1);
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+        {
+            const int n = min(n0 + bRowOf(i), p.Np - 1);
+            bOff[i] = ((unsigned)n * (unsigned)p.Kp + (unsigned)bOct * 8u + (bPlaneOf(i) ? planeDelta : 0u)) * 2u;
+        }
+    }
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
         if ((DMX_SPLIT_ABL & 16) && inLoop)
             return;
+        if constexpr (LIN)
+        {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+            {
+                aRegS[SET][i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.X) + aOff[i]);
+                aOff[i] += KT * 4;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+            {
+                bRegS[SET][i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.Wb1) + bOff[i]);
+                bOff[i] += KT * 2;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AR; ++i)
             aRegS[SET][i] = *reinterpret_cast<const f32x4 *>(w.addrA[i]);
@@ -155,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
                     Bp[0][0][0] = bRegS[SET][i];
                 continue;
             }
-            const int row = srow + i * RP;
-            Bp[bPlane][row][bOct ^ swz(row)] = bRegS[SET][i];
+            const int row = bRowOf(i);
+            Bp[bPlaneOf(i)][row][bOct ^ swz(row)] = bRegS[SET][i];
         }
     };
 
@@ -173,11 +221,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     // are read one row step ahead.
     const std::integral_constant<int, 0> set0{};
     const std::integral_constant<int, 1> set1{};
-    w.compute_addrs();
+    if (!LIN)
+        w.compute_addrs();
     issue_loads(set0);
-    w.compute_addrs();
+    if (!LIN)
+        w.compute_addrs();
     issue_loads(set1);
-    w.compute_addrs(); // tile 2
+    if (!LIN)
+        w.compute_addrs(); // tile 2
     store_tiles(set0, 0, 0, AR, 0, BR);
     __syncthreads();
     const int l15 = lane & 15, kq = lane >> 4;
@@ -227,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
                 acc[i][j] = DMX_SPLIT_MFMA(b1[j], a2, acc[i][j], 0, 0, 0);
-            if (i == WMF - 1)
+            if (!LIN && i == WMF - 1)
                 w.compute_addrs(); // addresses of tile kt+3
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
@@ -285,7 +336,9 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
     a.xcdMap = 1;
     a.dP0 = make_fastdiv((unsigned)a.P0), a.dP1 = make_fastdiv((unsigned)a.P1);
     const unsigned blocks = 8u * ((a.tilesM + 7u) / 8u) * a.tilesN;
-    const bool lin = gemm_is_linear(a, PRO, EPI, 32);
+    // (LIN also requires every staging offset to fit 32 bits: the kernel addresses a row as base + 32-bit byte offset)
+    const bool lin = gemm_is_linear(a, PRO, EPI, 32) && ((i64)a.B * a.xBS + 64) * 4 < (1ll << 32) &&
+                     ((i64)(a.Wb2 - a.Wb1) + (i64)a.Np * a.Kp + 64) * 2 < (1ll << 32);
     if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU))
     {
         if (lin)

@@ -169,6 +169,7 @@ struct IstftOlaArgs
     float *out;
     int B, T, S, seg, pad;
     int nch, fpc; // frame chunks per (batch, source) and frames per chunk (filled by the launcher)
+    const float *rden; // (1 / 4096) / (wss + 1e-8), same indexing as wss (plan.h Ola::rden)
 };
 void launch_istft_ola(const IstftOlaArgs &a, hipStream_t s);
 

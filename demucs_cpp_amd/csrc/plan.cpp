@@ -134,6 +134,12 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
 
 bool direct_available(int N, int S1, int seg0, int pro, int epi)
 {
+    // deep-level DConv k3 in column chunks of 192 (dgemm.hip launch_dgemm)
+    if (pro == PRO_GN_GELU && epi == EPI_GN_GLU_SCALE_RES && S1 == 1 && (seg0 == 24 || seg0 == 48) && N > 192 && N % 192 == 0)
+    {
+        const char *e = getenv("DMX_K3_CHUNKS"); // 0: keep the LDS-tiled kernel (A/B)
+        return !e || atoi(e) != 0;
+    }
     const int NF = (N + 15) / 16;
     const int key = NF * 1000000 + S1 * 100000 + seg0 * 100 + pro * 10 + epi;
     static const int keys[] = {
@@ -378,6 +384,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
     const int nfr = T + 4;
     const i64 wssLen = 4096 + 1024 * (i64)(nfr - 1);
     const i64 cWss = b.alloc(wssLen);
+    const i64 cRden = b.alloc(wssLen);
     const i64 cPe2 = b.alloc((i64)tokF * D);
     const i64 cPe1 = b.alloc((i64)tokT * D);
     pl.constants.assign((size_t)b.top, 0.0f);
@@ -399,6 +406,9 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         for (int i = 0; i < nfr; ++i)
             for (int j = 0; j < 4096; ++j)
                 wss[(i64)i * 1024 + j] += win[j] * win[j];
+        float *rden = &pl.constants[(size_t)cRden];
+        for (i64 n = 0; n < wssLen; ++n)
+            rden[n] = (1.0f / 4096.0f) / (wss[n] + 1e-8f);
         // 2-D sinusoidal embedding on tokens (t*8+f): crosstransformer.cpp:7-53,227-238
         float *pe2 = &pl.constants[(size_t)cPe2];
         {
@@ -796,7 +806,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         o2.kind = OP_OLA;
         o2.stream = 0;
         o2.name = "ola";
-        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle};
+        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle, cRden};
         pl.ops.push_back(o2);
     }
     compute_deps(pl);
@@ -1013,6 +1023,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOp
     const int nfr = T + 4;
     const i64 wssLen = 4096 + 1024 * (i64)(nfr - 1);
     const i64 cWss = b.alloc(wssLen);
+    const i64 cRden = b.alloc(wssLen);
     pl.constants.assign((size_t)b.top, 0.0f);
     {
         float *win = &pl.constants[(size_t)cWindow];
@@ -1031,6 +1042,9 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOp
         for (int i = 0; i < nfr; ++i)
             for (int j = 0; j < 4096; ++j)
                 wss[(i64)i * 1024 + j] += win[j] * win[j];
+        float *rden = &pl.constants[(size_t)cRden];
+        for (i64 n = 0; n < wssLen; ++n)
+            rden[n] = (1.0f / 4096.0f) / (wss[n] + 1e-8f);
     }
 
     // ------------------------------------------------------------------ activations
@@ -1458,7 +1472,7 @@ void build_plan_v3(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOp
         o2.kind = OP_OLA;
         o2.stream = 0;
         o2.name = "ola";
-        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle};
+        o2.ola = Ola{aFrames, aTDin[4], aStT, cWss, pl.outOff, B, T, S, (int)seg, (int)G.pad, aDin[4], aStF, cWindow, cTwiddle, cRden};
         pl.ops.push_back(o2);
     }
     pl.arenaFloats = b.top + 64;

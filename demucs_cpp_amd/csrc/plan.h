@@ -186,6 +186,8 @@ struct Ola
     i64 out;     // A: [B][S][2][seg] planar
     int B, T, S, seg, pad;
     i64 x, stats, window, twiddle; // operands of the preceding OP_ISTFT (fused execution), -1 otherwise
+    i64 rden;    // A constant, same indexing as wss: (1 / 4096) / (wss + 1e-8) - the fused GPU kernel multiplies by it instead of
+                 // dividing twice per term (<= 1 ulp per term from the reference's y / 4096 / (wss + 1e-8), dsp.cpp:151-185)
 };
 
 // ---- Demucs v3 ops. Tensors are [B][rows][C] channels-last like everything else.

@@ -85,7 +85,8 @@ extern "C"
      *                   number in the file - of two (w = w1 + w2: exact), and a w is accumulated in fp32 from five exact
      *                   partial products; the dropped a3 w2 is <= 2^-24 |a w|. MI355X's bf16 MFMA
      *                   rate is 16x its fp32 MFMA rate. Ops whose weights are not fp16-exact stay on the fp32 kernels.
-     * dmx_ctx_create uses the process default: environment DMX_GEMM=f32|bf16x3 read once, or dmx_set_default_gemm. A
+     * dmx_ctx_create uses the process default: DMX_GEMM_BF16X3 unless the environment says DMX_GEMM=f32 (read once), or
+     * what dmx_set_default_gemm set. A
      * context keeps its mode for life; contexts of both modes may coexist on one model. (No reference counterpart.) */
 #define DMX_GEMM_F32 0
 #define DMX_GEMM_BF16X3 1

@@ -9,6 +9,7 @@ Corrections (MI355X_MICROARCH.md §HBM): both counters are in KB; on gfx950 FETC
 library reads with 16-B/lane loads (float4), so the factor applies to all classes. WRITE_SIZE is
 taken as reported (uncalibrated per the guide)."""
 import json
+import os
 import sys
 
 sys.path.insert(0, __import__("os").path.dirname(__file__))
@@ -18,7 +19,7 @@ fa, fc, _ = aggregate(sys.argv[1], True)
 wa, wc, _ = aggregate(sys.argv[2], True)
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 out = {"_note": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches; rocprofv3 --pmc, separate passes, "
-                "bench.py --batch %d" % batch, "batch": batch, "classes": {}}
+                "bench.py --batch %d" % batch, "batch": batch, "gemm": os.environ.get("GEMM", "f32"), "model": os.environ.get("MODEL", "4s"), "classes": {}}
 for k in fa:
     if k not in wa:
         continue
