@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--no-track", action="store_true")
     ap.add_argument("--no-other-gemm", action="store_true", help="skip the secondary measurement of the other GEMM mode (N = 1)")
+    ap.add_argument("--no-split-probe", action="store_true", help=argparse.SUPPRESS)  # round-3 spelling (tools/gpu_r3*.sh): same as --no-other-gemm
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: TEST MODE ONLY - several ranks share GPU 0 and the gather goes through host memory, to "
                          "exercise the N > 1 control flow (double buffering, flush, overlap-add of all ranks' segments) on a "
@@ -343,7 +344,7 @@ def main():
 
     # ---- the other GEMM mode on the same workload, same process, same buffers (N = 1)
     other_run = None
-    if world == 1 and not args.no_other_gemm and not test_mode:
+    if world == 1 and not (args.no_other_gemm or args.no_split_probe) and not test_mode:
         ctx2 = dmx.Context(models[0], SEG, B, gemm=gemm_names[other])
         ctx2.set_stream(stream.cuda_stream)
         state["ctx"] = ctx2

@@ -41,8 +41,17 @@ __device__ __forceinline__ float4 ld4z(const float *ptr, bool ok, const float *z
 __device__ __forceinline__ float f4get(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 template <int NF, int S1, int SEG0, int PRO, int EPI, int PIPE>
-__global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs p, const FastDiv dP0, const FastDiv dP1)
+__global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs pa, const FastDiv dP0, const FastDiv dP1)
 {
+    // column chunks (launch_dgemm: the deep-level DConv k3): workgroups of grid row y own the packed columns
+    // [y N, (y + 1) N) of a wider op - N is the chunk width here - i.e. output channels [y N / 2, (y + 1) N / 2)
+    GemmArgs p = pa;
+    if (gridDim.y > 1)
+    {
+        const int n0 = (int)blockIdx.y * pa.N;
+        p.Wt += (i64)n0 * pa.Kp, p.bias += n0, p.epiW += n0, p.epiB += n0, p.scale += n0 / 2;
+        p.Y += n0 / 2, p.res += n0 / 2;
+    }
     constexpr int NV4 = SEG0 / 16;          // float4 steps per contiguous run
     constexpr int RPL = (SEG0 % 16) / 4;    // remainder floats per lane (0, 2 or 3)
     constexpr int NV4A = NV4 > 0 ? NV4 : 1; // array extents must not be 0
@@ -591,14 +600,14 @@ static bool k1_ring_ok(const GemmArgs &a)
 #define DMX_DG_PIPE -1 // -1: per-shape choice of the launch table; 0/1/2 force one pipeline (experiments)
 #endif
 template <int NF, int S1, int SEG0, int PRO, int EPI, int PIPE_>
-static void launch_d(const GemmArgs &a, hipStream_t s)
+static void launch_d(const GemmArgs &a, hipStream_t s, int chunks = 1)
 {
     const int nfrag = (int)((a.M + 15) >> 4);
     int blocks = (nfrag + 3) / 4;
-    if (blocks > 256 * 8)
-        blocks = 256 * 8; // persistent: 8 workgroups per CU at most, waves stride over fragments
+    if (blocks > 256 * 8 / chunks)
+        blocks = 256 * 8 / chunks; // persistent: 8 workgroups per CU at most, waves stride over fragments
     constexpr int PIPE = DMX_DG_PIPE >= 0 ? DMX_DG_PIPE : PIPE_;
-    hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI, PIPE>), dim3(blocks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
+    hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI, PIPE>), dim3(blocks, chunks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
                        make_fastdiv((unsigned)a.P1));
 }
 
@@ -637,17 +646,13 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
             // DMX_K3_CHUNK=96|192 for A/B runs; the default is the measured winner
             static const int chunkEnv = getenv("DMX_K3_CHUNK") ? atoi(getenv("DMX_K3_CHUNK")) : 0;
             const int cw = chunkEnv == 96 || chunkEnv == 192 ? chunkEnv : 96;
-            for (int n0 = 0; n0 < a.N; n0 += cw)
-            {
-                GemmArgs c = a;
-                c.Wt += (i64)n0 * a.Kp, c.bias += n0, c.epiW += n0, c.epiB += n0, c.scale += n0 / 2;
-                c.Y += n0 / 2, c.res += n0 / 2;
-                c.N = c.Np = cw;
-                if (cw == 192)
-                    a.seg0 == 24 ? launch_d<12, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1>(c, s) : launch_d<12, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s);
-                else
-                    a.seg0 == 24 ? launch_d<6, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s) : launch_d<6, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s);
-            }
+            GemmArgs c = a; // ONE launch: grid row y = chunk y (the kernel offsets its column-indexed operands by y * N)
+            c.N = c.Np = cw;
+            const int chunks = a.N / cw;
+            if (cw == 192)
+                a.seg0 == 24 ? launch_d<12, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 1>(c, s, chunks) : launch_d<12, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s, chunks);
+            else
+                a.seg0 == 24 ? launch_d<6, 1, 24, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s, chunks) : launch_d<6, 1, 48, PRO_GN_GELU, EPI_GN_GLU_SCALE_RES, 0>(c, s, chunks);
         }
         return 0;
     }

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-24}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-single --no-track --no-split-probe"
+CMD="python $R/bench.py --steps 2 --warmup 1 --batch $B --gemm ${GEMM:-bf16x3} --no-cpu-baseline --no-roofline --no-single --no-track --no-other-gemm"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d /tmp/pmcE -o e -- $CMD > /tmp/pmcE.log 2>&1
 f=$(find /tmp/pmcE -name "*.db" | head -1)
 tail -2 /tmp/pmcE.log

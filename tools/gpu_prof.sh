@@ -1,5 +1,6 @@
 #!/bin/bash
-# per-op HIP-event profile of a model at the batch sizes in $PBS (default "1 42"): gpurun_out/profile_ops_<model>_b<B>.tsv
+# per-op HIP-event profile of a model (MODEL=4s|6s|v3) at the batch sizes in $PBS (default "1 42"), GEMM mode from DMX_GEMM
+# (default: the library default, bf16x3): gpurun_out/profile_ops_<model>_b<B>.tsv
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 MODEL=${MODEL:-4s} PBS="${PBS:-1 42}" timeout 900 python - <<'PY' 2>&1 | tail -120
@@ -9,7 +10,7 @@ import numpy as np, torch
 from demucs_cpp_amd import binding as dmx
 from demucs_cpp_amd.weights import write_synthetic_model
 model = os.environ["MODEL"]
-write_synthetic_model('/tmp/pm.bin', 6 if model == "6s" else 4, 0, 'default', 'v3' if model == 'v3' else 'v4')
+write_synthetic_model('/tmp/pm.bin', 6 if model == "6s" else 4, 3 if model == "6s" else 0, 'default', 'v3' if model == 'v3' else 'v4')
 m = dmx.Model('/tmp/pm.bin')
 for PB in [int(x) for x in os.environ["PBS"].split()]:
     ctx = dmx.Context(m, 0, PB)
