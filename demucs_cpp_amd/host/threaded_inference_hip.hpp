@@ -35,88 +35,130 @@ const int SAMPLE_RATE = 44100;
 const float OVERLAP = 0.75f;
 const int OVERLAP_SAMPLES = (int)::floorf(SAMPLE_RATE * OVERLAP); // 33075
 
-// infer(chunk_index, chunk (2, n_i)) -> (S, 2, n_i)
-template <class Infer>
-demucscpp::StemTensor threaded_split_apply(const demucscpp::StereoMatrix &full_audio, int num_threads, int nb_out_sources, Infer infer)
+// Where the chunks of a track lie: chunk i covers track samples [begin(i), end(i)) and is handed to the model with
+// `context` samples of surroundings on either side (the reference's arithmetic: ceilf of a float quotient, :52-53).
+struct ChunkLayout
 {
-    using demucscpp::StemTensor;
-    using demucscpp::StereoMatrix;
-    const int64_t total_length = full_audio.cols();
-    const int64_t segment_length = (int64_t)::ceilf((float)total_length / (float)num_threads);
-    const int64_t OV = OVERLAP_SAMPLES;
-
-    std::vector<StereoMatrix> segments;
-    for (int i = 0; i < num_threads; ++i)
+    int64_t total = 0, span = 0, context = OVERLAP_SAMPLES;
+    int count = 1;
+    ChunkLayout(int64_t total_samples, int chunks) : total(total_samples), count(chunks < 1 ? 1 : chunks)
     {
-        const int64_t start = std::min<int64_t>(total_length, i * segment_length);
-        const int64_t end = std::min<int64_t>(total_length, start + segment_length);
-        StereoMatrix segment(end - start + 2 * OV); // zero filled
-        for (int64_t k = 0; k < OV; ++k)
-            for (int c = 0; c < 2; ++c)
-            {
-                if (i == 0)
-                    segment(c, k) = total_length > 0 ? full_audio(c, 0) : 0.0f;
-                else if (start - OV + k >= 0)
-                    segment(c, k) = full_audio(c, start - OV + k);
-            }
-        if (i != num_threads - 1)
-            for (int64_t k = 0; k < OV && end + k < total_length; ++k)
-                for (int c = 0; c < 2; ++c)
-                    segment(c, end - start + OV + k) = full_audio(c, end + k);
-        for (int64_t k = 0; k < end - start; ++k)
-            for (int c = 0; c < 2; ++c)
-                segment(c, OV + k) = full_audio(c, start + k);
-        segments.push_back(std::move(segment));
+        span = (int64_t)::ceilf((float)total / (float)count);
     }
+    int64_t begin(int i) const { return std::min<int64_t>(total, (int64_t)i * span); }
+    int64_t end(int i) const { return std::min<int64_t>(total, begin(i) + span); }
+    int64_t padded_length(int i) const { return end(i) - begin(i) + 2 * context; }
+    // track position of sample j of chunk i's padded signal (may fall outside [0, total))
+    int64_t track_index(int i, int64_t j) const { return (int64_t)i * span + j - context; }
+};
 
-    std::vector<StemTensor> segment_outs;
-    for (int i = 0; i < num_threads; ++i)
-        segment_outs.push_back(infer(i, segments[(size_t)i]));
-
-    StemTensor final_output(nb_out_sources, total_length);
-    std::vector<float> ramp((size_t)std::max<int64_t>(segment_length, 1));
-    float rmax = 0.f;
-    for (int64_t k = 0; k < segment_length; ++k)
+// The padded signal of chunk i: [ left context | the chunk | right context ]. Left of the first chunk the first track
+// sample is repeated, right of the last chunk (and beyond the end of the track) there is silence (:57-96).
+inline demucscpp::StereoMatrix cut_chunk(const demucscpp::StereoMatrix &track, const ChunkLayout &lay, int i)
+{
+    demucscpp::StereoMatrix padded(lay.padded_length(i)); // zero filled
+    const int64_t b = lay.begin(i), e = lay.end(i), ctx = lay.context;
+    const bool first = i == 0, last = i == lay.count - 1;
+    for (int c = 0; c < 2; ++c)
     {
-        ramp[(size_t)k] = (float)std::min(k + 1, segment_length - k);
-        rmax = std::max(rmax, ramp[(size_t)k]);
-    }
-    for (int64_t k = 0; k < segment_length; ++k)
-        ramp[(size_t)k] /= rmax;
-    std::vector<float> sum_weight((size_t)total_length, 0.0f);
-
-    for (size_t i = 0; i < segment_outs.size(); ++i)
-    {
-        const int64_t segment_start = (int64_t)i * segment_length;
-        const int64_t have = segment_outs[i].dimension(2);
-        for (int64_t j = 0; j < segment_length + 2 * OV && j < have; ++j)
+        for (int64_t k = 0; k < ctx; ++k)
         {
-            const int64_t g = segment_start + j - OV;
-            if (g < 0 || g >= total_length)
+            const int64_t src = b - ctx + k;
+            if (first)
+                padded(c, k) = lay.total > 0 ? track(c, 0) : 0.0f;
+            else if (src >= 0)
+                padded(c, k) = track(c, src);
+        }
+        for (int64_t k = 0; k < e - b; ++k)
+            padded(c, ctx + k) = track(c, b + k);
+        if (!last)
+            for (int64_t k = 0; k < ctx && e + k < lay.total; ++k)
+                padded(c, e - b + ctx + k) = track(c, e + k);
+    }
+    return padded;
+}
+
+// Cross-fade weights of the recombination: a triangle over one chunk span, normalised to a maximum of 1 (:134-139);
+// sample j of a padded chunk output rises along it through the left context, is 1 inside, and falls along its mirror image
+// from sample `span` on (:143-171).
+struct FadeWindow
+{
+    std::vector<float> ramp;
+    int64_t span, context;
+    FadeWindow(int64_t span_, int64_t context_) : ramp((size_t)std::max<int64_t>(span_, 1)), span(span_), context(context_)
+    {
+        float top = 0.f;
+        for (int64_t k = 0; k < span; ++k)
+        {
+            ramp[(size_t)k] = (float)std::min(k + 1, span - k);
+            top = std::max(top, ramp[(size_t)k]);
+        }
+        for (int64_t k = 0; k < span; ++k)
+            ramp[(size_t)k] /= top;
+    }
+    float at(int64_t k) const { return k >= 0 && k < span ? ramp[(size_t)k] : 0.0f; }
+    float weight(int64_t j) const
+    {
+        if (j < context)
+            return at(j);
+        if (j >= span)
+            return at(span + 2 * context - j - 1);
+        return 1.0f;
+    }
+};
+
+// Running weighted sum of chunk outputs and of their weights. The reference adds a sample's weight once per (target,
+// channel) and divides by (sum / (2 S)) at the end (:164-189); both quirks are part of the result's bits and are kept.
+class CrossfadeSum
+{
+  public:
+    CrossfadeSum(int sources, int64_t total) : out_(sources, total), wsum_((size_t)total, 0.0f), sources_(sources), total_(total) {}
+    void add(const demucscpp::StemTensor &chunk_out, const ChunkLayout &lay, const FadeWindow &fade, int i)
+    {
+        const int64_t have = chunk_out.dimension(2), n = std::min<int64_t>(lay.span + 2 * lay.context, have);
+        for (int64_t j = 0; j < n; ++j)
+        {
+            const int64_t g = lay.track_index(i, j);
+            if (g < 0 || g >= total_)
                 continue;
-            float weight = 1.0f;
-            if (j < OV)
-                weight = j < segment_length ? ramp[(size_t)j] : 0.0f;
-            else if (j >= segment_length)
-            {
-                const int64_t r = segment_length + 2 * OV - j - 1;
-                weight = (r >= 0 && r < segment_length) ? ramp[(size_t)r] : 0.0f;
-            }
-            for (int t = 0; t < nb_out_sources; ++t)
+            const float w = fade.weight(j);
+            for (int t = 0; t < sources_; ++t)
                 for (int ch = 0; ch < 2; ++ch)
                 {
-                    final_output(t, ch, g) += segment_outs[i](t, ch, j) * weight;
-                    sum_weight[(size_t)g] += weight; // once per (target, channel), like the reference
+                    out_(t, ch, g) += chunk_out(t, ch, j) * w;
+                    wsum_[(size_t)g] += w;
                 }
         }
     }
-    const float per = 2.0f * (float)nb_out_sources;
-    for (int64_t g = 0; g < total_length; ++g)
-        if (sum_weight[(size_t)g] > 0)
-            for (int t = 0; t < nb_out_sources; ++t)
-                for (int ch = 0; ch < 2; ++ch)
-                    final_output(t, ch, g) /= (sum_weight[(size_t)g] / per);
-    return final_output;
+    demucscpp::StemTensor finish()
+    {
+        const float per = 2.0f * (float)sources_;
+        for (int64_t g = 0; g < total_; ++g)
+            if (wsum_[(size_t)g] > 0)
+                for (int t = 0; t < sources_; ++t)
+                    for (int ch = 0; ch < 2; ++ch)
+                        out_(t, ch, g) /= (wsum_[(size_t)g] / per);
+        return std::move(out_);
+    }
+
+  private:
+    demucscpp::StemTensor out_;
+    std::vector<float> wsum_;
+    int sources_;
+    int64_t total_;
+};
+
+// infer(chunk_index, padded chunk (2, n_i)) -> (S, 2, n_i). Chunks are cut, separated and blended one at a time, in
+// track order (the blend's float additions happen in the reference's order: chunk by chunk, sample by sample).
+template <class Infer>
+demucscpp::StemTensor threaded_split_apply(const demucscpp::StereoMatrix &full_audio, int num_threads, int nb_out_sources, Infer infer)
+{
+    const ChunkLayout lay(full_audio.cols(), num_threads);
+    const FadeWindow fade(lay.span, lay.context);
+    CrossfadeSum sum(nb_out_sources, lay.total);
+    for (int i = 0; i < lay.count; ++i)
+        sum.add(infer(i, cut_chunk(full_audio, lay, i)), lay, fade, i);
+    return sum.finish();
 }
 
 // cli-apps/threaded_inference.hpp:29-33. `num_threads` chunks; progress lines carry the reference's

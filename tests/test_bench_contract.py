@@ -19,11 +19,14 @@ def test_bench_refuses_without_gpu():
     assert "needs a GPU" in (r.stdout + r.stderr)
 
 
-def _check_line(d, kernel_stats_csv):
+def _check_line(d, kernel_stats_csv, rnd=3, items=42, track_s=240.0):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "audio-sec/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["unit"] == "audio-sec/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    # dtype = the arithmetic type the path computes in: fp32 either way; since round 4 the products come from exact bf16
+    # operand splits and the string says so
+    assert d["dtype"] == ("f32" if rnd == 3 else "f32 (exact bf16x3 operand split, fp32 accumulate)")
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -32,14 +35,22 @@ def _check_line(d, kernel_stats_csv):
     cfg = d["config"]
     # round 3: a step is one 4-minute track (BASELINE configs[2]) resident in HBM; every other figure measured in the same
     # run is a SCALAR key of config (nested dicts do not survive the driver's `parsed`)
-    assert cfg["segments_per_gpu_per_step"] == 42 and cfg["track_samples_per_step"] == 240 * 44100
-    assert abs(d["value"] - 240.0 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert cfg["segments_per_gpu_per_step"] == items and cfg["track_samples_per_step"] == 240 * 44100
+    assert abs(d["value"] - track_s / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     for k, v in cfg.items():
         assert not isinstance(v, (dict, list)), k
     assert cfg["track_4min_host_xRT"] > 100 and cfg["track_4min_host_wall_s"] > 0 and cfg["track_4min_host_MB_in_out"] > 400
     assert cfg["track_strong_ranks"] == d["n_gpus"] and cfg["track_strong_xRT"] > 100 and cfg["single_segment_latency_ms"] > 0
-    assert cfg["gemm_path"].startswith("f32 MFMA")  # the headline never runs the opt-in operand-split experiment
-    assert cfg["experiment_bf16x3_split_xRT"] is None or cfg["experiment_bf16x3_split_xRT"] > d["value"]
+    if rnd == 3:
+        assert cfg["gemm_path"].startswith("f32 MFMA")  # round 3: the operand split was an opt-in experiment
+        assert cfg["experiment_bf16x3_split_xRT"] is None or cfg["experiment_bf16x3_split_xRT"] > d["value"]
+    else:
+        # round 4: the exact split is the product path; the fp32-MFMA context measured in the same run is beside it, and
+        # the dominant kernel is priced against the bf16 pipe divided by the partial products per fp32 term
+        assert cfg["gemm_path"].startswith("bf16x3") and cfg["outputs_finite"] is True
+        assert cfg["f32_mfma_xRT"] is not None and 0 < cfg["f32_mfma_xRT"] < d["value"] and cfg["f32_mfma_outputs_finite"] is True
+        assert (r["kernel"].startswith("igemm_split_") and r["peak"] == 503.3) or (r["kernel"] == "attention_split" and r["peak"] == 419.4)
+        assert "2516.6" in r["peak_basis"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "openblas_value", "openblas_kind"):
         assert k in c, k
@@ -62,6 +73,30 @@ def test_committed_v3_bench_line_schema():
     assert "hdemucs_mmi" in d["metric"]
     _check_line(d, "r03_kernel_stats_v3_b42_by_class.csv")
     assert d["config"]["single_segment_latency_ms"] > 4.0  # 2016 sequential LSTM steps alone are ~5 ms
+
+
+def test_committed_round4_bench_lines():
+    rd = lambda n: json.loads(open(os.path.join(ROOT, "profiles", n)).read())
+    d = rd("r04_bench_4s_b42.json")
+    assert "htdemucs-4s" in d["metric"] and "configs[2]" in d["metric"]
+    _check_line(d, "r04_kernel_stats_b42_by_class.csv", rnd=4)
+    assert d["value"] >= 2600 and d["config"]["ms_per_segment"] <= 2.2  # the round-3 review's target for the split path
+    v3 = rd("r04_bench_v3_b42.json")
+    assert "hdemucs_mmi" in v3["metric"]
+    _check_line(v3, "r04_kernel_stats_v3_b42_by_class.csv", rnd=4)
+    # BASELINE configs[3] / configs[4] at full size on one GPU: the 6-source model, and the fine-tuned bag whose step is
+    # 4 models x 42 segments and whose value still counts the track's seconds once
+    s6 = rd("r04_bench_6s_b42.json")
+    assert "htdemucs-6s" in s6["metric"] and "configs[3]" in s6["metric"] and s6["config"]["models"] == 1
+    assert s6["config"]["segments_per_gpu_per_step"] == 42 and s6["config"]["gemm_path"].startswith("bf16x3")
+    ft = rd("r04_bench_ft_b42.json")
+    assert "configs[4]" in ft["metric"] and ft["config"]["models"] == 4 and ft["config"]["segments_per_gpu_per_step"] == 168
+    assert abs(ft["value"] - 240.0 / (ft["ms_per_step"] * 1e-3)) / ft["value"] < 1e-3
+    assert 3.5 < d["value"] / ft["value"] < 4.5  # four models' work per second of track
+    # the batch sweep: ms per segment falls monotonically with the batch in both arithmetic modes
+    sweep = [json.loads(x) for x in open(os.path.join(ROOT, "profiles", "r04_bench_4s_b1_b4_b12_b24.jsonl")) if x.strip()]
+    ms = [x["config"]["ms_per_segment"] for x in sweep]
+    assert len(ms) == 4 and ms == sorted(ms, reverse=True) and ms[-1] > d["config"]["ms_per_segment"]
 
 
 def test_round2_bench_line_still_parses():
