@@ -370,12 +370,16 @@ struct StageWalk
 // The MFMAs are issued with the operands swapped (weights as A, activations as B), so each accumulator holds C^T:
 // lane (l15, kq) owns row m = tile row 16 i + l15 and the 4 CONSECUTIVE channels n = 16 j + 4 kq + {0..3} -> one
 // float4 global access per fragment, one row-info lookup per row fragment, 2-step cross-lane reduction for the row
-// statistics. rowinfo: tile row -> int4 (b, p1, p0, group); rsum: BM x WAVES_N scratch for the cross-wave row
+// statistics. rowinfo: tile row -> int4 (b, p1, p0, group); rsum: BM x (WAVES_N * SSEG) scratch for the cross-wave row
 // statistics (LDS; may alias a staging image that is no longer read - the caller synchronises before the call).
-template <int WAVES_N, int WMF, int WNF, int EPI, int NT, typename RowInfo>
-__device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[WMF][WNF], RowInfo rowinfo, float2 (*rsum)[WAVES_N], i64 m0,
+// SSEG: a wave's WNF column fragments are summed into the row statistics as SSEG separate runs of WNF / SSEG fragments,
+// each reduced on its own - a 1 x 8-fragment wave with SSEG = 2 adds in exactly the order of two 4-fragment waves, so
+// the statistics (and everything normalised with them) do not depend on which of the two wave layouts ran.
+template <int WAVES_N, int WMF, int WNF, int EPI, int NT, int SSEG = 1, typename RowInfo>
+__device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[WMF][WNF], RowInfo rowinfo, float2 (*rsum)[WAVES_N * SSEG], i64 m0,
                                                int n0, unsigned tileN, int wm, int wn, int BM)
 {
+    static_assert(WNF % SSEG == 0, "whole fragments per statistics run");
     const int tid = threadIdx.x, lane = tid & 63;
     const int l15 = lane & 15, kq = lane >> 4;
     const bool wantStats = p.rowstat != nullptr;
@@ -414,6 +418,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         const bool rowOk = ri.w >= 0;
         const i64 m = m0 + rl;
         float s = 0.f, ss = 0.f;
+        float sSeg[SSEG], ssSeg[SSEG]; // (SSEG > 1) finished runs
         // residual operands of the whole row are loaded FIRST (independent loads in flight), then
         // combined and stored: res may alias Y element-wise (in-place updates), every element is read
         // before the same lane overwrites it.
@@ -474,17 +479,28 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                     }
                 }
+                if (SSEG > 1 && (j + 1) % (WNF / SSEG) == 0)
+                {
+                    sSeg[j / (WNF / SSEG)] = s, ssSeg[j / (WNF / SSEG)] = ss;
+                    s = ss = 0.f;
+                }
             }
             if (wantStats)
             {
-                s += __shfl_xor(s, 16);
-                ss += __shfl_xor(ss, 16);
-                s += __shfl_xor(s, 32);
-                ss += __shfl_xor(ss, 32);
-                if (kq == 0)
+#pragma unroll
+                for (int q = 0; q < SSEG; ++q)
                 {
-                    rsum[rl][wn].x = s; // member-wise: a whole-struct store goes through a private-memory temporary
-                    rsum[rl][wn].y = ss;
+                    if (SSEG > 1)
+                        s = sSeg[q], ss = ssSeg[q];
+                    s += __shfl_xor(s, 16);
+                    ss += __shfl_xor(ss, 16);
+                    s += __shfl_xor(s, 32);
+                    ss += __shfl_xor(ss, 32);
+                    if (kq == 0)
+                    {
+                        rsum[rl][wn * SSEG + q].x = s; // member-wise: a whole-struct store goes through a private-memory temporary
+                        rsum[rl][wn * SSEG + q].y = ss;
+                    }
                 }
             }
         }
@@ -594,7 +610,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                 {
                     float s = 0.f, ss = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WAVES_N; ++w)
+                    for (int w = 0; w < WAVES_N * SSEG; ++w)
                     {
                         s += rsum[r][w].x;
                         ss += rsum[r][w].y;

@@ -307,6 +307,188 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     igemm_epilogue<WAVES_N, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wm, wn, BM);
 }
 
+// ---- linear layers with the activation fragments loaded straight into registers (no LDS image of A) -------------------
+//
+// A token-major operand ([row][K] floats, the transformer's layers) already has the shape of the matrix pipe's operand:
+// lane (l15, kq) of a 16x16x32 block needs row l15, k = 8 kq .. 8 kq + 7 = 32 contiguous bytes. Four waves stacked in M
+// (each WMF x 16 rows by the tile's whole width) fetch their own rows as two 16-byte loads per block and K-tile, split
+// them in registers and never write them to LDS; only the two weight planes are staged (16 KB per K-tile, read by all
+// four waves). Per 128x128 K-tile the workgroup moves 64 KB of fragment reads + 16 KB of plane stores through LDS
+// instead of 80 + 40 KB (the 2 x 2-wave kernel above: 94 of the CU's 128 B/clk at the matrix pipe's full rate), no
+// activation byte is fetched twice, and each element is still split exactly once.
+// The MFMA operands are the same 8-element groups in the same order as in the kernel above, so the results are the
+// same bits (the batch / shard invariance tests run small batches on the 2 x 2 kernels and large ones on this one).
+template <int WMF, int WNF, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs p)
+{
+    constexpr int KT = 32;
+    constexpr int BM = 4 * WMF * 16, BN = WNF * 16;
+    constexpr int BR = BN / 32; // 16-byte chunks of the two weight planes per thread and K-tile
+    static_assert(BN % 64 == 0, "two rows of one plane per 8-lane store group");
+    __shared__ u32x4 Bp0[2][BN][4], Bp1[2][BN][4]; // [plane][column][octet slot]
+    float2(*rsum)[2] = reinterpret_cast<float2(*)[2]>(&Bp0[0][0][0]); // after the K loop: two runs of four fragments per row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    unsigned tileM, tileN;
+    if (!tile_of_block(p, tileM, tileN))
+        return;
+    const i64 m0 = (i64)tileM * BM;
+    const int n0 = (int)tileN * BN;
+    auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
+
+    // activation rows of this lane: block i = rows wave * WMF * 16 + 16 i + l15, k-octet kq (rows beyond M read the last
+    // valid row; their accumulators are never stored)
+    unsigned aOff[WMF], bOff[BR];
+    {
+        const i64 rowLen = (i64)p.L0 * p.Cin;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            const i64 m = min(m0 + wave * (WMF * 16) + i * 16 + l15, p.M - 1);
+            const int4 ri = row_info(p, m);
+            aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
+        }
+    }
+    // weight chunks: chunk i = plane i & 1 of column 64 (i >> 1) + 2 (tid >> 3) + ((tid >> 2) & 1), octet tid & 3
+    const int bOct = tid & 3;
+    auto bRowOf = [&](int i) { return 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1); };
+    {
+        const unsigned planeDelta = (unsigned)(p.Wb2 - p.Wb1);
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+        {
+            const int n = min(n0 + bRowOf(i), p.Np - 1);
+            bOff[i] = ((unsigned)n * (unsigned)p.Kp + (unsigned)bOct * 8u + ((i & 1) ? planeDelta : 0u)) * 2u;
+        }
+    }
+
+    f32x4 aRaw[2][WMF][2];
+    u32x4 bReg[2][BR];
+    bf16x8 aPl[2][WMF][3];
+    auto issue_loads = [&](auto setTag) {
+        constexpr int SET = decltype(setTag)::value;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            const char *src = reinterpret_cast<const char *>(p.X) + aOff[i];
+            aRaw[SET][i][0] = *reinterpret_cast<const f32x4 *>(src);
+            aRaw[SET][i][1] = *reinterpret_cast<const f32x4 *>(src + 16);
+            aOff[i] += KT * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+        {
+            bReg[SET][i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.Wb1) + bOff[i]);
+            bOff[i] += KT * 2;
+        }
+    };
+    auto split_block = [&](auto setTag, int i) {
+        constexpr int SET = decltype(setTag)::value;
+        const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
+        unsigned h1[4], h2[4], h3[4];
+        split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
+        split3_pk(lo[2], lo[3], h1[1], h2[1], h3[1]);
+        split3_pk(hi[0], hi[1], h1[2], h2[2], h3[2]);
+        split3_pk(hi[2], hi[3], h1[3], h2[3], h3[3]);
+        u32x4 q1{h1[0], h1[1], h1[2], h1[3]}, q2{h2[0], h2[1], h2[2], h2[3]}, q3{h3[0], h3[1], h3[2], h3[3]};
+        // (the planes are computed HERE, between the MFMA groups: without this the compiler sinks the split of the odd
+        // tiles into the next iteration's head, in front of its first fragment reads)
+        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
+        aPl[SET][i][0] = __builtin_bit_cast(bf16x8, q1);
+        aPl[SET][i][1] = __builtin_bit_cast(bf16x8, q2);
+        aPl[SET][i][2] = __builtin_bit_cast(bf16x8, q3);
+    };
+    auto store_B = [&](auto setTag, int buf, int b0, int b1e) {
+        constexpr int SET = decltype(setTag)::value;
+        u32x4(*Bp)[BN][4] = buf ? Bp1 : Bp0;
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+        {
+            if (i < b0 || i >= b1e)
+                continue;
+            const int row = bRowOf(i);
+            Bp[i & 1][row][bOct ^ swz(row)] = bReg[SET][i];
+        }
+    };
+
+    f32x4 acc[WMF][WNF];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+        for (int j = 0; j < WNF; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // pipeline: iteration kt multiplies tile kt (weight image PAR, activation planes aPl[PAR]); at its start it requests
+    // tile kt + 2 into register set PAR, and between its MFMA groups it splits the activations of tile kt + 1 (set PAR ^ 1,
+    // requested a whole iteration earlier) and writes that tile's weight chunks into the other image. One barrier per tile.
+    const std::integral_constant<int, 0> set0{};
+    const std::integral_constant<int, 1> set1{};
+    const int nk = (p.Kp + 31) >> 5;
+    issue_loads(set0);
+    issue_loads(set1);
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+        split_block(set0, i);
+    store_B(set0, 0, 0, BR);
+    __syncthreads();
+    const int fslot = kq ^ swz(l15);
+    constexpr int NH = WNF / 4; // column fragments are processed four at a time
+    auto iteration = [&](auto parTag) {
+        constexpr int PAR = decltype(parTag)::value;
+        const std::integral_constant<int, PAR ^ 1> other{};
+        u32x4(*Bp)[BN][4] = PAR ? Bp1 : Bp0;
+        issue_loads(parTag); // tile kt + 2
+        bf16x8 b1[NH][4], b2[NH][4];
+        auto read_half = [&](int h) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int r = (h * 4 + j) * 16 + l15;
+                b1[h][j] = __builtin_bit_cast(bf16x8, Bp[0][r][fslot]);
+                b2[h][j] = __builtin_bit_cast(bf16x8, Bp[1][r][fslot]);
+            }
+        };
+        // one term of the product for the four column fragments of half h, all row blocks: 4 WMF independent accumulators
+        auto term = [&](int h, bf16x8(&b)[4], int plane) {
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][h * 4 + j] = DMX_SPLIT_MFMA(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
+        };
+        read_half(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+        {
+            // smallest terms first, as in igemm_split_kernel: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
+            term(h, b1[h], 2);
+            if (h + 1 < NH)
+                read_half(h + 1); // the next half's fragments are in flight during this half's remaining MFMAs
+            term(h, b2[h], 1);
+            // tile kt + 1: activations of set PAR ^ 1 -> planes, weight chunks -> the other image (spread over the halves)
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+                if ((i * NH) / WMF == h)
+                    split_block(other, i);
+            store_B(other, PAR ^ 1, h * BR / NH, (h + 1) * BR / NH);
+            term(h, b2[h], 0);
+            term(h, b1[h], 1);
+            term(h, b1[h], 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2)
+    {
+        iteration(set0);
+        if (kt + 1 < nk)
+            iteration(set1);
+    }
+    __syncthreads(); // (rsum aliases the weight image)
+    igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
+}
+
 // the kernels' activation split on an array (dmx_debug_split_activations: unit test of the split itself)
 __global__ void split3_debug_kernel(const float *x, i64 n, unsigned short *planes)
 {
@@ -343,6 +525,20 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
     {
         if (lin)
         {
+            // 128-wide tiles of at least 64 rows: activation fragments straight into registers (igemm_split_lin_kernel);
+            // same tile size and map, same bits. DMX_SPLIT_LIN=0 keeps the staged form (A/B comparison). Measured at 42
+            // segments: the 34 linear-layer launches 24.62 -> 24.44 ms - the loop is bound by the energy
+            // of the bytes it moves from L2, which this form does not change; a 256 x 128 tile with one workgroup per
+            // CU (one wave per SIMD, 445 registers) was 15 % slower and is not kept.
+            if constexpr (WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
+            {
+                static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+                if (mode == 1)
+                {
+                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, true>), dim3(blocks), dim3(256), 0, s, a);
             return;
         }
@@ -351,7 +547,8 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
 }
 
 // The MFMA-bound tile families only (plan.h kTileCfgs): 0 / 7 / 15 (2x2 waves, 4 column fragments), 9 / 16 (2 column
-// fragments), 2 / 10 (4x1 waves, 6 column fragments). Returns -1 for anything else: the op keeps its fp32 kernel.
+// fragments), 2 / 10 (4x1 waves, 6 column fragments), 3 / 11 (4x1 waves, 3 column fragments, plain convs only).
+// Returns -1 for anything else: the op keeps its fp32 kernel.
 int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
 {
     if (a.M >= (1ll << 31) - 256 || !a.Wb1 || !a.Wb2)
@@ -390,6 +587,11 @@ int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_LINEAR)
         DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_GLU)
         DMX_CASE(10, 4, 1, 1, 6, PRO_NONE, EPI_TRCONV)
+        // 48-wide tiles (4 x 1 waves, 3 column fragments): the deepest DConv K1 convs (K = 3 C = 1152, N = C / 8 = 48: 72 flops
+        // per byte, above what the fp32 MFMA feeds at HBM speed): 96-102 -> 118-143 TFLOP/s. The 32-wide tiles of the
+        // level below (N = 24) were measured on this path too: no change (88 split operations per 20 MFMAs), they keep fp32.
+        DMX_CASE(3, 4, 1, 2, 3, PRO_NONE, EPI_LINEAR)
+        DMX_CASE(11, 4, 1, 1, 3, PRO_NONE, EPI_LINEAR)
     default:
         return -1;
     }

@@ -20,6 +20,10 @@ def kernel_class(name: str) -> str:
     if m:
         wm, wn, mf, nf = (int(x) for x in m.groups())
         return f"igemm_split_{wm * mf * 16}x{wn * nf * 16}"
+    m = re.search(r"igemm_split_lin_kernel<(\d+), (\d+)", name)  # linear layers, activation fragments in registers: same tiles / class
+    if m:
+        mf, nf = (int(x) for x in m.groups())
+        return f"igemm_split_{4 * mf * 16}x{nf * 16}"
     if "igemm_lin256_kernel" in name:
         return "igemm_lin256x128"
     for key, cls in (("lstm_kernel", "lstm"), ("local_attn_kernel", "local_attn"), ("group_stats", "group_stats"), ("gn_act_kernel", "gn_act"),

@@ -14,7 +14,10 @@ B = int(os.environ.get("PB", "24"))
 ns = int(os.environ.get("NS", "4"))
 path = f"/tmp/prof_ops_{ns}s.bin"
 if not os.path.exists(path):
-    write_synthetic_model(path, ns, 0 if ns == 4 else 3)
+    if ns == 3:  # hdemucs_mmi (Demucs v3)
+        write_synthetic_model(path, 4, 5, "default", "v3")
+    else:
+        write_synthetic_model(path, ns, 0 if ns == 4 else 3)
 m = dmx.Model(path)
 ctx = dmx.Context(m, 0, B)
 prof = ctx.profile(B, int(os.environ.get("REPS", "3")))
