@@ -1418,17 +1418,26 @@ extern "C" int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name
             if (g.cfg == kDirectCfg)
                 return -1;
             const i64 nblk = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
+            // 8 words per tile, then (timing builds) 2 words per wave of the padded grid: epilogue-internal stamps
+            const i64 gridPad = nblk + 8 * (i64)g.NB + 64;
+            const i64 words = nblk * 8 + gridPad * 8;
             unsigned long long *d = nullptr;
-            if (hipMalloc((void **)&d, nblk * 64) != hipSuccess)
+            if (hipMalloc((void **)&d, words * 8) != hipSuccess)
                 return -1;
-            (void)hipMemset(d, 0, nblk * 64);
+            (void)hipMemset(d, 0, words * 8);
             g_dbg = d;
             launch_op(c, op, c->stream, p->zeroOff);
             g_dbg = nullptr;
             (void)hipStreamSynchronize(c->stream);
-            std::vector<unsigned long long> h((size_t)nblk * 8);
-            (void)hipMemcpy(h.data(), d, nblk * 64, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> h((size_t)words);
+            (void)hipMemcpy(h.data(), d, words * 8, hipMemcpyDeviceToHost);
             (void)hipFree(d);
+            if (const char *dump = getenv("DMX_TIMING_DUMP")) // raw per-workgroup records (8 x u64 each)
+                if (FILE *f = fopen(dump, "wb"))
+                {
+                    fwrite(h.data(), 8, h.size(), f);
+                    fclose(f);
+                }
             for (int i = 0; i < 6; ++i)
                 out[i] = 0;
             for (i64 b = 0; b < nblk; ++b)

@@ -380,6 +380,9 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                                                int n0, unsigned tileN, int wm, int wn, int BM)
 {
     static_assert(WNF % SSEG == 0, "whole fragments per statistics run");
+#ifdef DMX_TIMING
+    unsigned long long *dmx_epi_ts = reinterpret_cast<unsigned long long *>(p.dbg ? p.dbg + 8ll * p.tilesM * p.tilesN + 2ll * (blockIdx.x * 4 + (threadIdx.x >> 6)) : nullptr); // (debug: per wave)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int l15 = lane & 15, kq = lane >> 4;
     const bool wantStats = p.rowstat != nullptr;
@@ -410,23 +413,39 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         }
     }
 
+    // ---- pass 1: EVERY global load of the epilogue (residuals / tables / GroupNorm statistics of all WMF row blocks), then one
+    // wait. On gfx9 stores count in vmcnt like loads and the counter retires in order: a load issued after a store cannot be
+    // waited for without waiting for the store's acknowledgement, and the compiler, which loses the exact count across the
+    // row / column guards, waits with vmcnt(0). With the residual loads of row block i + 1 behind the stores of row block i
+    // (the first form of this function) every store of a tile was followed by a full L2 round trip before the next one was
+    // issued: 16 stores took 8 us of a 34 us linear-layer tile (tools/gpu_wg_timeline.py). res may alias Y element-wise
+    // (in-place updates): every element is read here before the same lane overwrites it below.
+    // Row blocks are taken in groups of G (at most 16 fragments of operands in registers: the 256-row tiles would spill):
+    // one wait - and one store round trip - per group.
+    constexpr int G = (16 / WNF) < 1 ? 1 : ((16 / WNF) > WMF ? WMF : (16 / WNF));
+    int4 riA[G];
+    float4 resA[G][WNF];
+    float meanA[G], scA[G];
+    i64 offsA[G][WNF]; // (EPI_TRCONV only; dead otherwise)
 #pragma unroll
-    for (int i = 0; i < WMF; ++i)
+    for (int g0 = 0; g0 < WMF; g0 += G)
     {
+#pragma unroll
+    for (int ig = 0; ig < G; ++ig)
+    {
+        const int i = g0 + ig;
+        if (i >= WMF)
+            break;
         const int rl = wm * (WMF * 16) + i * 16 + l15;
         const int4 ri = rowinfo(rl);
+        riA[ig] = ri;
         const bool rowOk = ri.w >= 0;
         const i64 m = m0 + rl;
-        float s = 0.f, ss = 0.f;
-        float sSeg[SSEG], ssSeg[SSEG]; // (SSEG > 1) finished runs
-        // residual operands of the whole row are loaded FIRST (independent loads in flight), then
-        // combined and stored: res may alias Y element-wise (in-place updates), every element is read
-        // before the same lane overwrites it.
-        float4 resv[WNF];
+        meanA[ig] = 0.f, scA[ig] = 1.f;
 #pragma unroll
         for (int j = 0; j < WNF; ++j)
-            resv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
+            resA[ig][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES)
         {
             if ((EPI == EPI_LINEAR && p.res) || EPI == EPI_SCALE_RES)
             {
@@ -435,9 +454,74 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                 {
                     const int n = colBase + j * 16;
                     if (rowOk && n < p.N)
-                        resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + n);
+                        resA[ig][j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + n);
                 }
             }
+        }
+        else if (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES)
+        {
+            if (EPI == EPI_GN_GLU_SCALE_RES && rowOk)
+            {
+                meanA[ig] = p.epiStats[ri.w * 4];
+                scA[ig] = p.epiStats[ri.w * 4 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < WNF; j += 2)
+            {
+                const int na = colBase + j * 16;
+                const int c = (na >> 5) * 16 + (na & 15);
+                if (rowOk && na + 16 < p.N)
+                {
+                    if (EPI == EPI_GN_GLU_SCALE_RES)
+                        resA[ig][j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + c);
+                    else if (p.table)
+                    {
+                        const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)ri.z * (p.N >> 1) + c);
+                        resA[ig][j] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
+                    }
+                }
+            }
+        }
+        else if (EPI == EPI_TRCONV)
+        {
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+            {
+                const int n = colBase + j * 16;
+                const int jj = p.trS * ri.z + trR[j] - p.trOff;
+                const i64 off = (rowOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j] : -1;
+                offsA[ig][j] = off;
+                if (p.res && off >= 0)
+                    resA[ig][j] = *reinterpret_cast<const float4 *>(p.res + off);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing below loads from global memory
+#ifdef DMX_TIMING
+    if (p.dbg && (threadIdx.x & 63) == 0)
+        dmx_epi_ts[0] = wall_clock64(); // every operand of the epilogue has arrived
+#endif
+
+    // ---- pass 2: arithmetic and stores (no global loads: the stores go out back to back)
+#pragma unroll
+    for (int ig = 0; ig < G; ++ig)
+    {
+        const int i = g0 + ig;
+        if (i >= WMF)
+            break;
+#ifdef DMX_TIMING
+        if (p.dbg && i == 1 && (threadIdx.x & 63) == 0)
+            dmx_epi_ts[1] = wall_clock64(); // first row block stored
+#endif
+        const int rl = wm * (WMF * 16) + i * 16 + l15;
+        const int4 ri = riA[ig];
+        const bool rowOk = ri.w >= 0;
+        const i64 m = m0 + rl;
+        float s = 0.f, ss = 0.f;
+        float sSeg[SSEG], ssSeg[SSEG]; // (SSEG > 1) finished runs
+        float4(&resv)[WNF] = resA[ig];
+        if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
+        {
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
             {
@@ -508,28 +592,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         {
             if constexpr (WNF % 2 == 0)
             {
-                float mean = 0.f, sc = 1.f;
-                if (EPI == EPI_GN_GLU_SCALE_RES && rowOk)
-                {
-                    mean = p.epiStats[ri.w * 4];
-                    sc = p.epiStats[ri.w * 4 + 1];
-                }
-#pragma unroll
-                for (int j = 0; j < WNF; j += 2)
-                {
-                    const int na = colBase + j * 16;
-                    const int c = (na >> 5) * 16 + (na & 15);
-                    if (rowOk && na + 16 < p.N)
-                    {
-                        if (EPI == EPI_GN_GLU_SCALE_RES)
-                            resv[j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + c);
-                        else if (p.table)
-                        {
-                            const float4 tv = *reinterpret_cast<const float4 *>(p.table + (i64)ri.z * (p.N >> 1) + c);
-                            resv[j] = make_float4(p.tableScale * tv.x, p.tableScale * tv.y, p.tableScale * tv.z, p.tableScale * tv.w);
-                        }
-                    }
-                }
+                const float mean = meanA[ig], sc = scA[ig];
 #pragma unroll
                 for (int j = 0; j < WNF; j += 2)
                 {
@@ -571,21 +634,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         }
         else // EPI_TRCONV
         {
-            i64 offs[WNF];
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-            {
-                const int n = colBase + j * 16;
-                const int jj = p.trS * ri.z + trR[j] - p.trOff;
-                offs[j] = (rowOk && n < p.N && jj >= 0 && jj < p.Lout) ? (i64)ri.x * p.yBS + ((i64)ri.y * p.Lout + jj) * p.ldy + trC[j] : -1;
-            }
-            if (p.res)
-            {
-#pragma unroll
-                for (int j = 0; j < WNF; ++j)
-                    if (offs[j] >= 0)
-                        resv[j] = *reinterpret_cast<const float4 *>(p.res + offs[j]);
-            }
+            i64(&offs)[WNF] = offsA[ig];
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
                 if (offs[j] >= 0)
@@ -599,6 +648,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                 }
         }
     }
+    } // groups of row blocks
     if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
         if (wantStats)
         {

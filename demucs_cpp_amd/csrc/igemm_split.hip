@@ -299,8 +299,16 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     __syncthreads(); // (rsum aliases the A image)
     if (DMX_SPLIT_ABL & 64)
     {
-        if (acc[0][0][0] == 123.456f)
-            p.Y[0] = acc[0][0][1];
+        // every accumulator stays live (a test of acc[0][0] alone lets the compiler delete 15 of 16 MFMAs: the first
+        // form of this switch "measured" the epilogue at 44 % of the linear layers)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (t == 123.456f)
+            p.Y[0] = t;
         return;
     }
 
@@ -333,6 +341,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     unsigned tileM, tileN;
     if (!tile_of_block(p, tileM, tileN))
         return;
+#ifdef DMX_TIMING
+    // per-workgroup timeline (make variant NAME=timing FLAGS=-DDMX_TIMING, dmx_debug_igemm_timing with DMX_TIMING_DUMP=file):
+    // 100 MHz wall clock at entry / loop start / loop end / epilogue issued / stores acknowledged, and where it ran
+    unsigned long long tstamp[5];
+    tstamp[0] = wall_clock64();
+#endif
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
     auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
@@ -366,8 +380,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     f32x4 aRaw[2][WMF][2];
     u32x4 bReg[2][BR];
     bf16x8 aPl[2][WMF][3];
+    bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
+        if ((DMX_SPLIT_ABL & 16) && inLoop)
+            return;
 #pragma unroll
         for (int i = 0; i < WMF; ++i)
         {
@@ -387,10 +404,20 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         constexpr int SET = decltype(setTag)::value;
         const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
         unsigned h1[4], h2[4], h3[4];
-        split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
-        split3_pk(lo[2], lo[3], h1[1], h2[1], h3[1]);
-        split3_pk(hi[0], hi[1], h1[2], h2[2], h3[2]);
-        split3_pk(hi[2], hi[3], h1[3], h2[3], h3[3]);
+        if (DMX_SPLIT_ABL & 1)
+        {
+            h1[0] = h2[0] = h3[0] = __builtin_amdgcn_perm(__float_as_uint(lo[1]), __float_as_uint(lo[0]), 0x07060302u);
+            h1[1] = h2[1] = h3[1] = __builtin_amdgcn_perm(__float_as_uint(lo[3]), __float_as_uint(lo[2]), 0x07060302u);
+            h1[2] = h2[2] = h3[2] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
+            h1[3] = h2[3] = h3[3] = __builtin_amdgcn_perm(__float_as_uint(hi[3]), __float_as_uint(hi[2]), 0x07060302u);
+        }
+        else
+        {
+            split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
+            split3_pk(lo[2], lo[3], h1[1], h2[1], h3[1]);
+            split3_pk(hi[0], hi[1], h1[2], h2[2], h3[2]);
+            split3_pk(hi[2], hi[3], h1[3], h2[3], h3[3]);
+        }
         u32x4 q1{h1[0], h1[1], h1[2], h1[3]}, q2{h2[0], h2[1], h2[2], h2[3]}, q3{h3[0], h3[1], h3[2], h3[3]};
         // (the planes are computed HERE, between the MFMA groups: without this the compiler sinks the split of the odd
         // tiles into the next iteration's head, in front of its first fragment reads)
@@ -407,6 +434,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         {
             if (i < b0 || i >= b1e)
                 continue;
+            if (DMX_SPLIT_ABL & 4)
+            {
+                if (bReg[SET][i][0] == 0x12345678u && bReg[SET][i][3] == 0x9abcdef0u)
+                    Bp[0][0][0] = bReg[SET][i];
+                continue;
+            }
             const int row = bRowOf(i);
             Bp[i & 1][row][bOct ^ swz(row)] = bReg[SET][i];
         }
@@ -434,12 +467,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     __syncthreads();
     const int fslot = kq ^ swz(l15);
     constexpr int NH = WNF / 4; // column fragments are processed four at a time
+    bf16x8 b1[NH][4], b2[NH][4];
+    bool inLoop2 = false; // (ablation 256: fragments are read in the first iteration only)
     auto iteration = [&](auto parTag) {
         constexpr int PAR = decltype(parTag)::value;
         const std::integral_constant<int, PAR ^ 1> other{};
         u32x4(*Bp)[BN][4] = PAR ? Bp1 : Bp0;
         issue_loads(parTag); // tile kt + 2
-        bf16x8 b1[NH][4], b2[NH][4];
         auto read_half = [&](int h) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -457,13 +491,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
                 for (int j = 0; j < 4; ++j)
                     acc[i][h * 4 + j] = DMX_SPLIT_MFMA(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
         };
-        read_half(0);
+        if (!(DMX_SPLIT_ABL & 256) || !inLoop2)
+            read_half(0);
 #pragma unroll
         for (int h = 0; h < NH; ++h)
         {
             // smallest terms first, as in igemm_split_kernel: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
             term(h, b1[h], 2);
-            if (h + 1 < NH)
+            if (h + 1 < NH && (!(DMX_SPLIT_ABL & 256) || !inLoop2))
                 read_half(h + 1); // the next half's fragments are in flight during this half's remaining MFMAs
             term(h, b2[h], 1);
             // tile kt + 1: activations of set PAR ^ 1 -> planes, weight chunks -> the other image (spread over the halves)
@@ -477,8 +512,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             term(h, b1[h], 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!(DMX_SPLIT_ABL & 8))
+            __syncthreads();
+        inLoop2 = true;
     };
+    inLoop = true;
+#ifdef DMX_TIMING
+    tstamp[1] = wall_clock64();
+#endif
     for (int kt = 0; kt < nk; kt += 2)
     {
         iteration(set0);
@@ -486,7 +527,38 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             iteration(set1);
     }
     __syncthreads(); // (rsum aliases the weight image)
+#ifdef DMX_TIMING
+    tstamp[2] = wall_clock64();
+#endif
+    if (DMX_SPLIT_ABL & 64)
+    {
+        // every accumulator stays live (a test of acc[0][0] alone lets the compiler delete 15 of 16 MFMAs: the first
+        // form of this switch "measured" the epilogue at 44 % of the linear layers)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (t == 123.456f)
+            p.Y[0] = t;
+        return;
+    }
     igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
+#ifdef DMX_TIMING
+    tstamp[3] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tstamp[4] = wall_clock64();
+    if (p.dbg && tid == 0)
+    {
+        unsigned long long *d = p.dbg + ((i64)tileN * p.tilesM + tileM) * 8;
+        for (int i = 0; i < 5; ++i)
+            d[i] = tstamp[i];
+        d[5] = (unsigned long long)nk;
+        d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
+        d[7] = blockIdx.x;
+    }
+#endif
 }
 
 // the kernels' activation split on an array (dmx_debug_split_activations: unit test of the split itself)

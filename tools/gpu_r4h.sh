@@ -3,5 +3,5 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-( MIX_SET=2 timeout 400 tools/micro/mfma_mix 2>&1 ) > gpurun_out/r4h_mfma_mix2.log
-cat gpurun_out/r4h_mfma_mix2.log
+( MIX_SET=4 timeout 400 tools/micro/mfma_mix 2>&1 ) > gpurun_out/r4h_mfma_mix4.log
+cat gpurun_out/r4h_mfma_mix4.log

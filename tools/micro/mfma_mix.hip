@@ -15,8 +15,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0>
-__global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, int iters, size_t window)
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0>
+__global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, int iters, size_t window, unsigned strideA, unsigned strideB)
 {
     __shared__ u32x4 lds[4096]; // 64 KB: [0, 2048) is read, [2048, 4096) is written
     const int tid = threadIdx.x;
@@ -57,12 +57,36 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
         gprev[j] = u32x4{1u, 2u, 3u, 4u};
     for (int it = 0; it < iters; ++it)
     {
+        if (ND > 0)
+        {
+            // direct global -> LDS loads (no VGPR round trip, no ds_write): lane l's 16 bytes land at base + 16 l
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(src) + ((goff + (8 + j) * 1048576u + j * 4096u) & mask),
+                                                 (__attribute__((address_space(3))) void *)&lds[2048 + 64 * ((tid >> 6) + 4 * j) + 256 * (it & 1)], 16, 0, 0);
+        }
         if (NG > 0)
         {
+            if (strideA)
+            {
+                // the GEMM's pattern: 8 lanes read 128 contiguous bytes of one row, 32 rows per load, rows strideA / strideB bytes
+                // apart; an "activation" row tile is shared by the 16 workgroups of a tile row, a "weight" tile by a tile column
+                const unsigned rowA = (blockIdx.x >> 4) * 128u + (tid >> 3), rowB = (blockIdx.x & 15u) * 128u + (tid >> 3);
+                const unsigned kb = (unsigned)it * 128u + (tid & 7u) * 16u;
 #pragma unroll
-            for (int j = 0; j < NG; ++j)
-                g[j] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(src) + ((goff + j * 1048576u + j * 4096u) & mask));
-            goff = (goff + 256u * 16u * 4099u) & mask;
+                for (int j = 0; j < NG; ++j)
+                {
+                    const unsigned off = j < NG / 2 ? (rowA + 32u * j) * strideA + kb : (1u << 29) + (rowB + 32u * (j - NG / 2)) * strideB + (kb >> 1);
+                    g[j] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(src) + (off & mask));
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < NG; ++j)
+                    g[j] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(src) + ((goff + j * 1048576u + j * 4096u) & mask));
+                goff = (goff + 256u * 16u * 4099u) & mask;
+            }
         }
         constexpr int LPG = NL > 0 ? NL / 4 : 0; // fragment reads per group of 20 MFMAs (at most 8), one group ahead
         if (NL > 0 && DEP)
@@ -124,23 +148,24 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
 }
 
 static int g_iters = 40000;
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0>
+static unsigned g_strideA = 0, g_strideB = 0;
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0>
 static void run(const char *tag, float *sink, const u32x4 *src, size_t window, int cus)
 {
     const int iters = g_iters, wgs = cus * WPS;
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window, g_strideA, g_strideB);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window, g_strideA, g_strideB);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)wgs * 4 * iters * 80 * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    printf("%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", tag, NV, NL, NG, BAR, NW, DEP, WPS, ms,
+    printf("%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
            tf, tf / 5, tf / 2516.6);
     fflush(stdout);
 }
@@ -210,6 +235,35 @@ int main()
         run<1, 20, 4, 1, 2, 10, 1>("4 loads, 10 writes, reads after barrier", sink, src, win, cus);
         run<2, 20, 8, 1, 2, 10, 1>("2 VALU, 8 loads, 10 writes, reads after barrier", sink, src, win, cus);
         run<1, 20, 8, 0, 2, 10, 0>("no barrier: 8 loads, 10 writes", sink, src, win, cus);
+    }
+    if (set == 3)
+    {
+        // weight planes by direct global -> LDS loads instead of load + ds_write
+        const size_t win = (size_t)16 << 20;
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1>("staged GEMM: 8 loads, 10 writes", sink, src, win, cus);
+        run<1, 20, 4, 1, 2, 6, 1, 4>("A staged (4 loads, 6 writes) + 4 direct-to-LDS", sink, src, win, cus);
+        run<1, 16, 8, 1, 2, 4, 1>("LIN kernel: 8 loads, 4 writes, 16 reads", sink, src, win, cus);
+        run<1, 16, 4, 1, 2, 0, 1, 4>("LIN kernel: 4 loads + 4 direct-to-LDS, 16 reads", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1>("staged GEMM again", sink, src, win, cus);
+        run<1, 16, 8, 1, 2, 4, 1>("LIN kernel again", sink, src, win, cus);
+    }
+    if (set == 4)
+    {
+        // does the address pattern of the loads matter? (rows a power of two apart vs a pseudo-random walk)
+        const size_t win = (size_t)1024 << 20;
+        g_iters = 64; // 64 K-tiles = K 2048, then the same rows again (run() repeats the kernel)
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, win, cus);
+        g_iters = 20000;
+        run<1, 16, 8, 1, 2, 4, 1>("LIN kernel, random walk", sink, src, win, cus);
+        for (unsigned sa : {2048u, 8192u, 2048u + 128u, 8192u + 128u})
+        {
+            g_strideA = sa, g_strideB = sa / 2;
+            char tag[96];
+            snprintf(tag, sizeof tag, "LIN kernel, rows %u / %u bytes apart", g_strideA, g_strideB);
+            run<1, 16, 8, 1, 2, 4, 1>(tag, sink, src, win, cus);
+        }
+        g_strideA = g_strideB = 0;
     }
     return 0;
 }
