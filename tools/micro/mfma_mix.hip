@@ -13,9 +13,10 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0>
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0>
 __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, int iters, size_t window, unsigned strideA, unsigned strideB)
 {
     __shared__ u32x4 lds[4096]; // 64 KB: [0, 2048) is read, [2048, 4096) is written
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 accB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            accB[j][e] = 0.f;
     bf16x8 f[2][8]; // fragment registers: 4 "weight" + 4 "activation" per set, two sets
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -117,7 +124,14 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
             for (int m = 0; m < 20; ++m)
             {
                 // volatile asm: exactly one MFMA, then its NV VALU companions, in this order, no packing
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
+                if (BIG)
+                {
+                    // the same flops from half as many instructions: 32x32x16 (32 pipe cycles each), 4 accumulators of 16 registers
+                    if (m & 1)
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accB[(m >> 1) & 3]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
+                }
+                else
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
                     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(m * NV + k) & 7]) : "v"(ca), "v"(cb));
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3] + v[j];
+        s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3] + v[j] + accB[j & 3][j] + accB[j & 3][15 - j];
     s += (float)(gacc[0] ^ gacc[1] ^ gacc[2] ^ gacc[3]);
     if (s == 123.456f)
         sink[0] = s;
@@ -149,23 +163,23 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
 
 static int g_iters = 40000;
 static unsigned g_strideA = 0, g_strideB = 0;
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0>
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0>
 static void run(const char *tag, float *sink, const u32x4 *src, size_t window, int cus)
 {
     const int iters = g_iters, wgs = cus * WPS;
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window, g_strideA, g_strideB);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window, g_strideA, g_strideB);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window, g_strideA, g_strideB);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window, g_strideA, g_strideB);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)wgs * 4 * iters * 80 * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    printf("%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
+    printf("%s%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", BIG ? "[32x32x16] " : "", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
            tf, tf / 5, tf / 2516.6);
     fflush(stdout);
 }
@@ -264,6 +278,24 @@ int main()
             run<1, 16, 8, 1, 2, 4, 1>(tag, sink, src, win, cus);
         }
         g_strideA = g_strideB = 0;
+    }
+    if (set == 5)
+    {
+        // half as many MFMA instructions for the same flops: v_mfma_f32_32x32x16_bf16 against 16x16x32
+        const size_t win = (size_t)16 << 20;
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, win, cus);
+        run<0, 0, 0, 0, 2>("MFMA only", sink, src, win, cus);
+        run<0, 0, 0, 0, 2, 0, 0, 0, 1>("MFMA only", sink, src, win, cus);
+        run<2, 0, 0, 0, 2>("2 VALU per 16x16x32", sink, src, win, cus);
+        run<2, 0, 0, 0, 2, 0, 0, 0, 1>("2 VALU per 16x16x32", sink, src, win, cus);
+        run<3, 0, 0, 0, 2>("3 VALU per 16x16x32", sink, src, win, cus);
+        run<3, 0, 0, 0, 2, 0, 0, 0, 1>("3 VALU per 16x16x32", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1>("staged GEMM: 1 VALU, 20 reads, 8 loads, 10 writes", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1, 0, 1>("staged GEMM: 1 VALU, 20 reads, 8 loads, 10 writes", sink, src, win, cus);
+        run<2, 20, 8, 1, 2, 10, 1>("conv GEMM: 2 VALU, 20 reads, 8 loads, 10 writes", sink, src, win, cus);
+        run<2, 20, 8, 1, 2, 10, 1, 0, 1>("conv GEMM: 2 VALU, 20 reads, 8 loads, 10 writes", sink, src, win, cus);
+        run<1, 16, 8, 1, 2, 4, 1>("LIN kernel: 16 reads, 4 writes", sink, src, win, cus);
+        run<1, 16, 8, 1, 2, 4, 1, 0, 1>("LIN kernel: 16 reads, 4 writes", sink, src, win, cus);
     }
     return 0;
 }
