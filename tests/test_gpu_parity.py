@@ -1016,6 +1016,28 @@ def test_cli_shards_over_dmx_devices_and_finish_modes(dmx, tmp_models, tmp_path)
         assert np.array_equal(a, b), ("ft", i)
 
 
+def test_linear_layer_split_kernels_agree_bitwise(tmp_path):
+    """The linear layers of a bf16x3 context run on igemm_split_lin_kernel (activation fragments loaded straight into
+    registers, 4 x 1 waves of 8 column fragments) or, with DMX_SPLIT_LIN=0, on the staged 2 x 2-wave kernel: same tile map,
+    same MFMA operand groups in the same order, row statistics summed as two runs of four fragments - so 4s and 6s tracks
+    are the same bits, with one segment per call (small tiles, staged kernel either way) and with six. The switch is read
+    once per process: two child processes (tools/gpu_lin_ab.py)."""
+    import subprocess
+    outs = []
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"lin_{mode}.npz")
+        env = dict(os.environ, DMX_SPLIT_LIN=mode)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_lin_ab.py"), "run", out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out)
+    a, b = np.load(outs[0]), np.load(outs[1])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 4
+    for k in a.files:
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
+    for which in ("4s", "6s"):
+        assert np.array_equal(b[f"{which}_track_b1"], b[f"{which}_track_b6"]), which
+
+
 def test_gemm_modes_coexist_in_one_process_and_split_error_is_not_worse(tmp_models, golden_dir):
     """DMX_GEMM_F32 and DMX_GEMM_BF16X3 contexts on ONE model handle in one process (the mode belongs to the context, not
     to the process): both against the fp64 golden model - the exact-split path (a = a1 + a2 + a3, w = w1 + w2, five exact
