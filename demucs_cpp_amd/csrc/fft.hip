@@ -307,17 +307,22 @@ void launch_ola(const OlaArgs &a, hipStream_t s)
 // SAME XCD, adjacent in dispatch order, so the lines come from HBM once and from that XCD's L2 afterwards.
 template <int PH>
 __device__ __forceinline__ void istft_ola_step(const IstftOlaArgs &p, float2 (&acc)[4][4], const float2 *bufA, int f, int tid, bool add,
-                                               bool emit, int b, int src, float meanT, float stdT)
+                                               bool emit, int b, int src, float meanT, float stdT, const float (&wreg)[16], const float (&rdI)[4])
 {
     if (add)
     {
+        // (1 / 4096) / (wss + 1e-8): one table entry per position of the padded signal (plan.cpp). Where all four overlapping
+        // frames exist - frames 3 .. T of the T + 4 - the window sum-square, summed in frame order, is the same float for
+        // every position with the same offset in its hop: 4 registers per thread instead of 16 loads per frame (and the
+        // window's 16 values are the thread's own in every frame). Only the first and the last frame read the table.
+        const bool edge = f < 3 || f > p.T;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
         {
             const int i = tid + 256 * j;
             const float2 z = bufA[FSW(i)]; // `bufA` here is the buffer that holds the transformed frame
-            const float w = p.window[i];
-            const float rd = p.rden[f * 1024 + i]; // (1 / 4096) / (wss + 1e-8), one table entry per position (plan.cpp)
+            const float w = wreg[j];
+            const float rd = edge ? p.rden[f * 1024 + i] : rdI[j & 3];
             const float y0 = z.x * w, y1 = z.y * w; // the value istft_kernel stores in `frames`
             float2 &a = acc[(PH + (j >> 2)) & 3][j & 3];
             a.x += y0 * rd; // the reference divides, y / 4096 / (wss + 1e-8) per term (dsp.cpp:151-185): <= 1 ulp apart
@@ -384,6 +389,13 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
         for (int m = 0; m < 8; ++m)
             xr[m] = *reinterpret_cast<const f32x4 *>(xin + (i64)(tid + 256 * m) * CS);
     };
+    float wreg[16], rdI[4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        wreg[j] = p.window[tid + 256 * j];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        rdI[c] = p.rden[3072 + tid + 256 * c]; // frame 3, first hop: an interior position
     const int fBeg = max(2, t0 + 2 - 3);
     fetch(fBeg);
     __syncthreads(); // twS
@@ -421,16 +433,16 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
         switch (f & 3)
         {
         case 0:
-            istft_ola_step<0>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<0>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         case 1:
-            istft_ola_step<1>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<1>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         case 2:
-            istft_ola_step<2>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<2>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         default:
-            istft_ola_step<3>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT);
+            istft_ola_step<3>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         }
         __syncthreads(); // bufB is rewritten by the next frame's transform
@@ -440,13 +452,30 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
 void launch_istft_ola(const IstftOlaArgs &a0, hipStream_t s)
 {
     IstftOlaArgs a = a0;
-    // enough workgroups for ~4 per CU; every chunk recomputes a 3-frame halo, so no shorter than 8 frames
-    const int want = (1024 + a.B * a.S - 1) / (a.B * a.S);
-    a.nch = want < 1 ? 1 : want;
-    if (a.nch > a.T / 8)
-        a.nch = a.T / 8 > 0 ? a.T / 8 : 1;
-    a.fpc = (a.T + a.nch - 1) / a.nch;
-    a.nch = (a.T + a.fpc - 1) / a.fpc;
+    // Chunks per (batch item, source): every chunk recomputes a 3-frame halo and loads the twiddles (~2 frames' worth), so
+    // no shorter than 8 frames - and the workgroups run in ROUNDS of two per CU (80 KB of LDS each), all the same length:
+    // the launch lasts rounds x (frames per chunk + 5). The first form asked for "about four workgroups per CU" and got
+    // 1184 workgroups = 2.3 rounds at 42 segments: the third round ran a third full. Take the chunk count with the
+    // shortest launch (42 x 4 sources: 3 chunks = 504 workgroups, one round, 1.39 -> 1.05 ms; chunk boundaries do not
+    // change a bit: every hop is summed in frame order).
+    static int slots = 0;
+    if (!slots)
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    const int maxch = a.T / 8 > 0 ? a.T / 8 : 1;
+    long best = -1;
+    for (int n = 1; n <= maxch; ++n)
+    {
+        const int fpc = (a.T + n - 1) / n, nch = (a.T + fpc - 1) / fpc;
+        const long wgs = 8l * ((long)(a.B * nch + 7) / 8) * a.S;
+        const long cost = ((wgs + slots - 1) / slots) * (long)(fpc + 5);
+        if (best < 0 || cost < best)
+            best = cost, a.nch = nch, a.fpc = fpc;
+    }
     const unsigned groups = (unsigned)(a.B * a.nch);
     hipLaunchKernelGGL(istft_ola_kernel, dim3(8u * ((groups + 7u) / 8u) * (unsigned)a.S), dim3(256), 0, s, a);
 }
