@@ -166,3 +166,17 @@ def test_weight_split_is_exact_for_every_fp16_value(dmx):
     w1, _, _ = dmx.split_weights(np.array([np.inf, -np.inf, np.nan], np.float32))
     t = (w1.astype(np.uint32) << 16).view(np.float32)
     assert t[0] == np.inf and t[1] == -np.inf and np.isnan(t[2])
+
+
+def test_every_environment_switch_of_the_product_is_documented():
+    """INTEGRATION.md's environment table names every DMX_* variable the library, the shim and the CLIs read."""
+    import re
+    names = set()
+    for sub in ("demucs_cpp_amd/csrc", "demucs_cpp_amd/host", "cli"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, sub)):
+            for f in fs:
+                if f.endswith((".cpp", ".hip", ".h", ".hpp")):
+                    names |= set(re.findall(r'getenv\("(DMX_[A-Z0-9_]+)"\)', open(os.path.join(dp, f), errors="replace").read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 20 and not missing, missing
