@@ -16,7 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0>
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0, int MPG = 20>
 __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, int iters, size_t window, unsigned strideA, unsigned strideB)
 {
     __shared__ u32x4 lds[4096]; // 64 KB: [0, 2048) is read, [2048, 4096) is written
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
                     f[nxt][j] = __builtin_bit_cast(bf16x8, lds[(tid + 64 * (grp * LPG + j) + it) & 2047]);
             }
 #pragma unroll
-            for (int m = 0; m < 20; ++m)
+            for (int m = 0; m < MPG; ++m) // MPG MFMAs per group, four groups per iteration
             {
                 // volatile asm: exactly one MFMA, then its NV VALU companions, in this order, no packing
                 if (BIG)
@@ -163,23 +163,23 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
 
 static int g_iters = 40000;
 static unsigned g_strideA = 0, g_strideB = 0;
-template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0>
+template <int NV, int NL, int NG, int BAR, int WPS, int NW = 0, int DEP = 0, int ND = 0, int BIG = 0, int MPG = 20>
 static void run(const char *tag, float *sink, const u32x4 *src, size_t window, int cus)
 {
     const int iters = g_iters, wgs = cus * WPS;
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window, g_strideA, g_strideB);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG, MPG>), dim3(wgs), dim3(256), 0, 0, sink, src, 200, window, g_strideA, g_strideB);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window, g_strideA, g_strideB);
+    hipLaunchKernelGGL((mix<NV, NL, NG, BAR, WPS, NW, DEP, ND, BIG, MPG>), dim3(wgs), dim3(256), 0, 0, sink, src, iters, window, g_strideA, g_strideB);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)wgs * 4 * iters * 80 * 16384.0;
+    const double flops = (double)wgs * 4 * iters * (4 * MPG) * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    printf("%s%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", BIG ? "[32x32x16] " : "", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
+    printf("[%d MFMAs / iteration, %.3f us per iteration] %s%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", 4 * MPG, ms * 1e3 / iters, BIG ? "[32x32x16] " : "", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
            tf, tf / 5, tf / 2516.6);
     fflush(stdout);
 }
@@ -296,6 +296,19 @@ int main()
         run<2, 20, 8, 1, 2, 10, 1, 0, 1>("conv GEMM: 2 VALU, 20 reads, 8 loads, 10 writes", sink, src, win, cus);
         run<1, 16, 8, 1, 2, 4, 1>("LIN kernel: 16 reads, 4 writes", sink, src, win, cus);
         run<1, 16, 8, 1, 2, 4, 1, 0, 1>("LIN kernel: 16 reads, 4 writes", sink, src, win, cus);
+    }
+    if (set == 6)
+    {
+        // one 64 x 64 x 32 wave tile-step of the split GEMM per iteration, two ways of forming the fp32 product:
+        // bf16 terms (a = 3 terms, w = 2 terms: 80 MFMAs, 20 fragment reads, 8 loads, 10 staging stores, 88 split operations)
+        // fp16 terms (a = 3 terms, w = 1 exact term: 48 MFMAs, 16 reads, 6 loads, 8 stores, the same split work)
+        const size_t win = (size_t)16 << 20;
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1, 0, 0, 20>("bf16 terms: 5 MFMAs per block", sink, src, win, cus);
+        run<2, 16, 6, 1, 2, 8, 1, 0, 0, 12>("fp16 terms: 3 MFMAs per block", sink, src, win, cus);
+        run<1, 20, 8, 1, 2, 10, 1, 0, 0, 20>("bf16 terms again", sink, src, win, cus);
+        run<2, 16, 6, 1, 2, 8, 1, 0, 0, 12>("fp16 terms again", sink, src, win, cus);
+        run<0, 0, 0, 0, 2, 0, 0, 0, 0, 12>("48 MFMAs only", sink, src, win, cus);
     }
     return 0;
 }
