@@ -1,6 +1,6 @@
 // quant_sgemm.c — CPU study of operand-split arithmetics (NOT product code, NOT the oracle): a cblas_sgemm-shaped function
 // that quantises the activation operand the way a split GEMM would see it and then multiplies in fp32, bound into the
-// oracle through its BLAS hook (oracle_lib.orc_use_blas) by tools/study/split_study.py.
+// oracle through its BLAS hook (oracle_lib.orc_use_blas) by tests/study/split_study.py.
 //   QMODE=f32          nothing (the plain fp32 chain of this file: the baseline of the study)
 //   QMODE=bf16x3       a = a1 + a2 + a3 (bf16, round to nearest), w = w1 + w2; the dropped a3 w2 is subtracted
 //   QMODE=fp16x3row    a 2^s = h1 + h2 + h3 (fp16, round to nearest), s per ROW from the row's max; w one exact fp16 term

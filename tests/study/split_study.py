@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""CPU study (no GPU, not product code): what would operand splits with fp16 terms do to the results?
+"""CPU study (no GPU; test infrastructure like the oracle it drives, not product code): what would operand splits with fp16
+terms do to the results?
 
-Binds tools/study/quant_sgemm.c into the ORACLE through its BLAS hook, so every convolution / linear layer of the
+Binds tests/study/quant_sgemm.c into the ORACLE through its BLAS hook, so every convolution / linear layer of the
 oracle sees its activation operand quantised the way a split GEMM would see it (QK^T and PV stay fp32), and compares
   * the default synthetic models with the fp64 torch goldens (tests/golden/golden_seg_{4s,6s}.npz), and
   * the stress models (dc, illcond, initscale, input gains) with the oracle's own plain fp32 run.
-    python tools/study/split_study.py [--quick]
+    python tests/study/split_study.py [--quick]
 """
 import ctypes
 import os
@@ -15,7 +16,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/study/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as orc  # noqa: E402
@@ -27,7 +28,7 @@ MODES = ["f32", "bf16x3", "fp16x3row", "fp16x3mat", "fp16x3"]
 def build():
     so = os.path.join(tempfile.gettempdir(), "libquant_sgemm.so")
     subprocess.check_call(["gcc", "-O2", "-march=native", "-mf16c", "-fopenmp", "-shared", "-fPIC", "-o", so,
-                           os.path.join(ROOT, "tools", "study", "quant_sgemm.c"), "-lm"])
+                           os.path.join(ROOT, "tests", "study", "quant_sgemm.c"), "-lm"])
     return so
 
 
