@@ -124,12 +124,14 @@ __global__ __launch_bounds__(256, WPS) void mix(float *sink, const u32x4 *src, i
             for (int m = 0; m < MPG; ++m) // MPG MFMAs per group, four groups per iteration
             {
                 // volatile asm: exactly one MFMA, then its NV VALU companions, in this order, no packing
-                if (BIG)
+                if (BIG == 1)
                 {
                     // the same flops from half as many instructions: 32x32x16 (32 pipe cycles each), 4 accumulators of 16 registers
                     if (m & 1)
                         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accB[(m >> 1) & 3]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
                 }
+                else if (BIG == 2)
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
                 else
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(f[cur][m & 3]), "v"(f[cur][4 + ((m >> 2) & 3)]));
 #pragma unroll
@@ -179,7 +181,7 @@ static void run(const char *tag, float *sink, const u32x4 *src, size_t window, i
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)wgs * 4 * iters * (4 * MPG) * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    printf("[%d MFMAs / iteration, %.3f us per iteration] %s%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", 4 * MPG, ms * 1e3 / iters, BIG ? "[32x32x16] " : "", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
+    printf("[%d MFMAs / iteration, %.3f us per iteration] %s%-44s NV=%d NL=%2d NG=%d BAR=%d NW=%2d DEP=%d ND=%d waves/SIMD=%d : %7.3f ms  %7.1f TFLOP/s bf16 = %5.1f fp32-equivalent (x/5) = %.3f of peak\n", 4 * MPG, ms * 1e3 / iters, BIG == 1 ? "[32x32x16] " : BIG == 2 ? "[f16] " : "", tag, NV, NL, NG, BAR, NW, DEP, ND, WPS, ms,
            tf, tf / 5, tf / 2516.6);
     fflush(stdout);
 }
@@ -309,6 +311,16 @@ int main()
         run<1, 20, 8, 1, 2, 10, 1, 0, 0, 20>("bf16 terms again", sink, src, win, cus);
         run<2, 16, 6, 1, 2, 8, 1, 0, 0, 12>("fp16 terms again", sink, src, win, cus);
         run<0, 0, 0, 0, 2, 0, 0, 0, 0, 12>("48 MFMAs only", sink, src, win, cus);
+    }
+    if (set == 7)
+    {
+        // v_mfma_f32_16x16x32_f16 against ..._bf16: the same pipe rate? (random bit patterns as operands either way)
+        const size_t win = (size_t)16 << 20;
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, win, cus);
+        run<0, 0, 0, 0, 2>("MFMA only", sink, src, win, cus);
+        run<0, 0, 0, 0, 2, 0, 0, 0, 2>("MFMA only", sink, src, win, cus);
+        run<2, 16, 6, 1, 2, 8, 1, 0, 0, 12>("fp16-term tile-step with the bf16 instruction", sink, src, win, cus);
+        run<2, 16, 6, 1, 2, 8, 1, 0, 2, 12>("fp16-term tile-step", sink, src, win, cus);
     }
     return 0;
 }
