@@ -58,3 +58,9 @@ variant:
 	for f in igemm igemm_split igemm_lin256 dgemm fft misc attention attention_split resample v3; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
 	for f in api engine plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so build/$(NAME)/*.o
+# one file rebuilt with other flags, the rest of the product's objects unchanged:
+#   make variant1 NAME=fftnoslp FILE=fft FLAGS=-fno-slp-vectorize   ->  demucs_cpp_amd/lib/libdemucs_hip_fftnoslp.so
+variant1: $(LIB)
+	@mkdir -p build/$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$(FILE).hip -o build/$(NAME)/$(FILE).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so $(filter-out build/$(FILE).o,$(OBJS)) build/$(NAME)/$(FILE).o -ldl -lpthread

@@ -927,7 +927,9 @@ static int run_plan(dmx_ctx *c, int batch)
     }
     // plan lane (see "device lanes"): ordered behind the previous plan run of this device while a bf16x3 context exists
     LstmLane *lane = lstm_lane(c->m->device);
-    const bool laneOn = lane && (lane->nSplit.load() > 0 || (lane->shared && lane->shared->nSplit.load() > 0));
+    // DMX_PLAN_LANE=0 (diagnostics only: tools/gpu_fft_erratum.sh, the opt-in half of the GPU stress test) switches the ordering off
+    static const bool planLaneOff = getenv("DMX_PLAN_LANE") && atoi(getenv("DMX_PLAN_LANE")) == 0;
+    const bool laneOn = lane && !planLaneOff && (lane->nSplit.load() > 0 || (lane->shared && lane->shared->nSplit.load() > 0));
     std::unique_lock<std::mutex> planLock;
     if (laneOn)
     {

@@ -137,6 +137,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int t = blockIdx.x, b = blockIdx.y;
+#ifdef DMX_FFT_LDS_PAD // diagnostic builds: a larger LDS footprint changes which workgroups can share the CU
+    __shared__ char ldsPad[DMX_FFT_LDS_PAD];
+    if (p.T < 0)
+        ldsPad[tid] = 1;
+#endif
     const float2 *tw = reinterpret_cast<const float2 *>(p.twiddle);
     const float2 *mix = reinterpret_cast<const float2 *>(p.mix) + (i64)b * p.seg;
 
@@ -356,6 +361,11 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
     __shared__ float2 twS[2048]; // twiddles in LDS: a chunk of ~30 frames amortises the 16 KB; the one-frame-per-workgroup
                                  // kernels above take them from L1/L2 (3 loads per butterfly and stage in the dependency chain)
     const int tid = threadIdx.x;
+#ifdef DMX_FFT_LDS_PAD
+    __shared__ char ldsPad[DMX_FFT_LDS_PAD];
+    if (p.T < 0)
+        ldsPad[tid] = 1;
+#endif
     // workgroup -> (group = (b, chunk), source): all sources of a group on one XCD (block id % 8)
     const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
     const int src = (int)(jq % (unsigned)p.S);
