@@ -3,7 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
 as one rank per GPU by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
-environment, backend "nccl" = RCCL). Rank 0 prints ONE JSON line.
+environment, backend "nccl" = RCCL) - or, started from a bare shell without WORLD_SIZE, it launches those N ranks itself
+(torch.distributed.run on a free local port). Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): htdemucs-4s, synthetic dmc4 weights
 (seed 0), a ~4-minute synthetic 44.1 kHz stereo track 0.1*N(0,1) RESIDENT IN HBM, fp32 in / fp32 out. One step on every
@@ -110,6 +111,27 @@ def pmc_traffic(kernel_class, batch, model="4s", gemm="f32"):
         return None, None
 
 
+def committed_clock(kernel_class, gemm="bf16x3"):
+    """Sustained shader clock of a kernel class under the bench workload, from the newest committed GRBM_GUI_ACTIVE pass
+    (profiles/rNN_effective_clock[_f32].csv, tools/gpu_clock.sh: busy cycles / 8 XCDs / duration). The peaks on the line are
+    priced at the 2.4 GHz maximum; this says how much of the distance to the peak is clock, not kernel."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_effective_clock" + ("" if gemm != "f32" else "_f32") + ".csv")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            lines = [l for l in f if l.startswith("class,") or (l.count(",") == 3 and not l.startswith("W"))]
+        for r in csv.DictReader(lines):
+            if r["class"] == kernel_class:
+                return float(r["effective_clock_GHz_per_XCD"]), "profiles/" + os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,9 +162,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: launch the N ranks ourselves (same command line under torch.distributed.run on a
+        # free local port); rank 0 of the child job prints the one JSON line, this process only forwards the exit code
+        import socket
+        import subprocess
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}; the launcher's world size is used", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     test_mode = args.backend == "gloo"
@@ -447,6 +480,10 @@ def main():
         traffic, traffic_src = pmc_traffic(kname, B, args.model, primary)
         peak = kernel_peak(kname)
         seg_flops = MODEL_FLOPS.get("4s" if ft else args.model)
+        # whole path against its own roofline: every op priced at max(algorithmic FLOPs / the matrix peak of ITS kernel class,
+        # algorithmic bytes / 8 TB/s), summed, over the measured sum of kernel time (1 = every op on its roof)
+        roof_ms = sum(max(fl_ / (kernel_peak(k_) * 1e12), by_ / 8.0e12) * 1e3 for _, k_, _, fl_, by_ in prof)
+        clock_ghz, clock_src = committed_clock(kname, primary)
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -456,6 +493,9 @@ def main():
             "kernel_share_of_device_time": round(ms / tot_ms, 3),
             "sum_of_kernel_ms_per_step": round(tot_ms * M, 3),
             "whole_path_tflops": round((seg_flops * B if seg_flops else sum(v[1] for v in by_kernel.values())) / (tot_ms * 1e-3) / 1e12, 2),
+            "whole_path_frac": round(roof_ms / tot_ms, 4),
+            "traffic_ratio": None if not traffic else round(traffic / (by / cnt), 3),
+            "effective_clock_ghz": clock_ghz, "effective_clock_source": clock_src, "peak_clock_ghz": 2.4,
             "peak_basis": ("fp32 MFMA v_mfma_f32_16x16x4_f32" if peak == PEAK_TFLOPS_FP32_MFMA else
                            f"bf16 MFMA dense {PEAK_TFLOPS_BF16_MFMA} TFLOP/s / {round(PEAK_TFLOPS_BF16_MFMA / peak)} exact partial products per fp32 term"),
         }
@@ -545,9 +585,12 @@ def main():
         }
         seg_flops = MODEL_FLOPS.get("4s" if ft else args.model)
         if single_ms is not None and seg_flops:
-            # the latency point against the fp32 MFMA roofline: the model's FLOPs in one call
+            # the latency point (configs[1] read literally) against the matrix peak of the arithmetic that RAN: the model's
+            # FLOPs in one call / (503.3 for the exact-split GEMMs, 157.3 for fp32 MFMA)
+            single_peak = PEAK_TFLOPS_FP32_MFMA if primary == "f32" else PEAK_TFLOPS_BF16_MFMA / 5
             line["config"]["single_segment_tflops"] = round(seg_flops / (single_ms * 1e-3) / 1e12, 2)
-            line["config"]["single_segment_roofline_frac"] = round(seg_flops / (single_ms * 1e-3) / 1e12 / PEAK_TFLOPS_FP32_MFMA, 4)
+            line["config"]["single_segment_roofline_frac"] = round(seg_flops / (single_ms * 1e-3) / 1e12 / single_peak, 4)
+            line["config"]["single_segment_peak_tflops"] = round(single_peak, 1)
         if roofline:
             line["roofline"] = roofline
         if cpu_baseline:

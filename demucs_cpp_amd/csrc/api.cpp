@@ -18,6 +18,7 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <pthread.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -87,6 +88,8 @@ extern "C" int dmx_default_gemm(void)
         // section 7.2); DMX_GEMM=f32 selects the fp32 MFMA kernels
         const char *e = getenv("DMX_GEMM");
         g = e && !strcmp(e, "f32") ? DMX_GEMM_F32 : DMX_GEMM_BF16X3;
+        if (e && *e && strcmp(e, "f32") && strcmp(e, "bf16x3")) // a typo must not silently select the other arithmetic
+            fprintf(stderr, "demucs_hip: DMX_GEMM=%s is not one of {f32, bf16x3}; using bf16x3 (the default)\n", e);
         g_defaultGemm.store(g);
     }
     return g;
@@ -280,23 +283,20 @@ static Plan *get_plan(dmx_ctx *c, int batch)
 // captures (batches below 8: at most 48 spinning workgroups per launch, i.e. ten concurrently replaying contexts fit)
 // stay outside, a capture cannot wait on a foreign event. Lanes are created on demand, one per visible device, and live
 // until the process ends (their events are not destroyed from a static destructor: the HIP runtime may be gone by then).
+// Several PROCESSES on one GPU (bench.py --backend gloo) take turns through a robust process-shared mutex in POSIX shared
+// memory keyed by the GPU's PCI bus id; who is "registered on this GPU" is a table of process ids whose liveness is checked
+// with kill(pid, 0), so a process that dies without running its exit handlers leaves nothing behind.
 //
-// PLAN lane (round 4). Contexts of DMX_GEMM_BF16X3 must not run concurrently with ANOTHER context's work on the same GPU:
-// with two contexts on one device (logical devices of an engine, the threads of the C++ shim), single 16-bin blocks of
-// single STFT / ISTFT frames of one context came out wrong while the other context's bf16 MFMA kernels were resident -
-// never with fp32 MFMA kernels, never with the bf16 kernels' MFMAs compiled out (their loads, splits, LDS traffic and
-// barriers alone do not do it), not reproduced by an LDS-privacy micro-benchmark (tools/micro/lds_overlap.hip) and not by
-// one context alone, whose FFT kernels never overlap its split kernels (gpurun_out diagnostics tools/gpu_diag_split*.py;
-// DESIGN.md section 7.5). Cause not established (it looks like a platform problem); the library's answer is ordering: while a
-// bf16x3 context exists on a device, every plan run on that device waits for the previous one's completion event, whatever
-// context or stream issued it, and - when several PROCESSES share the GPU and one of them holds a bf16x3 context - plan
-// runs take turns through the process-shared mutex. One context per GPU (the deployment case, and one process per GPU in
-// bench.py) never waits.
+// (Round 4 also had a PLAN lane here that serialised whole plan runs of different contexts of a device while a bf16x3
+// context existed. It contained a corruption of FFT frames whose cause round 5 found: packed fp32 VALU instructions with
+// half routing miscompute next to 16-bit MFMAs of another wave - DESIGN.md section 7, tools/micro/pk_f32_erratum.hip. The
+// library is now built without packed fp32 arithmetic (Makefile NOPK, tests/test_isa_rules.py), and the lane is gone:
+// contexts that share a GPU overlap again.)
 struct SharedLane // one per GPU in POSIX shared memory, keyed by the PCI bus id
 {
+    static const int kSlots = 64;
     std::atomic<int> ready;
-    std::atomic<int> nprocs;
-    std::atomic<int> nSplit; // bf16x3 contexts alive on this GPU, all processes
+    std::atomic<int> pid[kSlots]; // processes registered on this GPU (0 = free); dead ones are reclaimed
     pthread_mutex_t mu;
 };
 struct LstmLane
@@ -305,26 +305,47 @@ struct LstmLane
     hipEvent_t ev = nullptr;
     bool recorded = false;
     SharedLane *shared = nullptr;
-    // plan lane
-    std::mutex planMu;
-    hipEvent_t planEv = nullptr;
-    bool planRecorded = false;
-    std::atomic<int> nSplit{0}; // bf16x3 contexts of this process on this device
 };
-static thread_local bool t_sharedHeld = false; // this thread holds the process-shared mutex (plan level): the LSTM level must not take it again
 static std::mutex g_lanesMu;
 static std::vector<std::unique_ptr<LstmLane>> g_lanes;
 static std::vector<SharedLane *> g_sharedRegistered;
+
+static bool pid_alive(int pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || errno != ESRCH); }
+
+// other live processes registered on the lane's GPU (dead entries are cleared on the way)
+static int shared_lane_peers(SharedLane *sl)
+{
+    const int self = (int)getpid();
+    int n = 0;
+    for (int i = 0; i < SharedLane::kSlots; ++i)
+    {
+        int p = sl->pid[i].load(std::memory_order_acquire);
+        if (p == 0 || p == self)
+            continue;
+        if (pid_alive(p))
+            ++n;
+        else
+            sl->pid[i].compare_exchange_strong(p, 0);
+    }
+    return n;
+}
 
 static SharedLane *open_shared_lane(int device)
 {
     if (const char *e = getenv("DMX_LSTM_SHARED_LANE"))
         if (atoi(e) == 0)
             return nullptr;
+    auto give_up = [](const char *what) -> SharedLane * {
+        // not fatal (one process per GPU never needs it), but not silent either: concurrent v3 PROCESSES on this GPU would
+        // then issue the cooperative LSTM kernel unordered (a starved launch raises the status word, it cannot hang)
+        fprintf(stderr, "demucs_hip: the process-shared LSTM lane is unavailable (%s: %s); several Demucs v3 processes on one GPU are not ordered\n", what,
+                strerror(errno));
+        return nullptr;
+    };
     char bus[64] = "";
     if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess)
         return nullptr;
-    std::string name = "/dmx_lstm_lane_";
+    std::string name = "/dmx_lane2_"; // (layout 2: pid table; round 4's counters lived in /dmx_lstm_lane_*)
     for (const char *q = bus; *q; ++q)
         name += (isalnum((unsigned char)*q) ? *q : '_');
     bool creator = true;
@@ -335,12 +356,12 @@ static SharedLane *open_shared_lane(int device)
         fd = shm_open(name.c_str(), O_RDWR, 0666);
     }
     if (fd < 0)
-        return nullptr;
+        return give_up("shm_open");
     if (creator && ftruncate(fd, sizeof(SharedLane)) != 0)
     {
         close(fd);
         shm_unlink(name.c_str());
-        return nullptr;
+        return give_up("ftruncate");
     }
     void *mem = MAP_FAILED;
     for (int tries = 0; tries < 200 && mem == MAP_FAILED; ++tries) // a second opener may arrive before the creator's ftruncate
@@ -353,7 +374,7 @@ static SharedLane *open_shared_lane(int device)
     }
     close(fd);
     if (mem == MAP_FAILED)
-        return nullptr;
+        return give_up("mmap");
     SharedLane *sl = static_cast<SharedLane *>(mem);
     if (creator)
     {
@@ -363,24 +384,47 @@ static SharedLane *open_shared_lane(int device)
         pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST);
         pthread_mutex_init(&sl->mu, &at);
         pthread_mutexattr_destroy(&at);
-        sl->nprocs.store(0);
-        sl->nSplit.store(0);
+        for (int i = 0; i < SharedLane::kSlots; ++i)
+            sl->pid[i].store(0);
         sl->ready.store(1, std::memory_order_release);
     }
     else
         for (int tries = 0; tries < 2000 && sl->ready.load(std::memory_order_acquire) != 1; ++tries)
             usleep(1000);
     if (sl->ready.load(std::memory_order_acquire) != 1)
-        return nullptr;
-    sl->nprocs.fetch_add(1);
+    {
+        errno = ETIMEDOUT;
+        return give_up("creator never finished");
+    }
+    // register: a free slot, or one whose owner is dead
+    const int self = (int)getpid();
+    bool registered = false;
+    for (int i = 0; i < SharedLane::kSlots && !registered; ++i)
+    {
+        int p = sl->pid[i].load();
+        if (p == self)
+            registered = true;
+        else if (p == 0 || !pid_alive(p))
+            registered = sl->pid[i].compare_exchange_strong(p, self);
+    }
+    if (!registered)
+    {
+        errno = ENOSPC;
+        return give_up("pid table full");
+    }
     g_sharedRegistered.push_back(sl);
     static bool hooked = false;
     if (!hooked)
     {
         hooked = true;
         atexit([] {
+            const int me = (int)getpid();
             for (SharedLane *l : g_sharedRegistered)
-                l->nprocs.fetch_sub(1);
+                for (int i = 0; i < SharedLane::kSlots; ++i)
+                {
+                    int p = me;
+                    l->pid[i].compare_exchange_strong(p, 0);
+                }
         });
     }
     return sl;
@@ -406,42 +450,26 @@ static LstmLane *lstm_lane(int device)
     return g_lanes[(size_t)device].get();
 }
 
-static void plan_lane_leave(int device)
-{
-    if (LstmLane *lane = lstm_lane(device))
-    {
-        lane->nSplit.fetch_sub(1);
-        if (lane->shared)
-            lane->shared->nSplit.fetch_sub(1);
-    }
-}
-
-// holds the process-shared mutex of a lane while another process is registered on the same GPU
+// holds the process-shared mutex of a lane while another live process is registered on the same GPU
 struct SharedLaneGuard
 {
     SharedLane *sl = nullptr;
-    explicit SharedLaneGuard(SharedLane *l, bool want = true)
+    explicit SharedLaneGuard(SharedLane *l)
     {
-        if (l && want && !t_sharedHeld && l->nprocs.load() > 1)
+        if (l && shared_lane_peers(l) > 0)
         {
             const int rc = pthread_mutex_lock(&l->mu);
             if (rc == EOWNERDEAD)
                 pthread_mutex_consistent(&l->mu);
             if (rc == 0 || rc == EOWNERDEAD)
-            {
                 sl = l;
-                t_sharedHeld = true;
-            }
         }
     }
     bool held() const { return sl != nullptr; }
     ~SharedLaneGuard()
     {
         if (sl)
-        {
-            t_sharedHeld = false;
             pthread_mutex_unlock(&sl->mu);
-        }
     }
 };
 
@@ -481,14 +509,6 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&c->hStatus, sizeof(unsigned), hipHostMallocDefault));
     *c->hStatus = 0;
-    if (gemm == DMX_GEMM_BF16X3)
-        if (LstmLane *lane = lstm_lane(m->device)) // from now on the plan runs of this device are ordered (device lanes)
-        {
-            lane->nSplit.fetch_add(1);
-            if (lane->shared)
-                lane->shared->nSplit.fetch_add(1);
-            c->inPlanLane = true;
-        }
     return DMX_OK;
 }
 
@@ -520,7 +540,6 @@ extern "C" int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, 
 // mutex; a launch only enqueues (tens of microseconds), so the device threads lose no overlap.
 static std::mutex g_graphMutex;
 
-static void plan_lane_leave(int device);
 dmx_ctx::~dmx_ctx()
 {
     if (!m)
@@ -528,8 +547,6 @@ dmx_ctx::~dmx_ctx()
     (void)hipSetDevice(m->device);
     if (stream)
         (void)hipStreamSynchronize(stream);
-    if (inPlanLane)
-        plan_lane_leave(m->device);
     {
         std::lock_guard<std::mutex> graphLock(g_graphMutex);
         for (auto &kv : graphs)
@@ -572,6 +589,17 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
     if (m->device != c->m->device || m->pm.arch != c->m->pm.arch || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
         m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
+    if (m->inexactW != c->m->inexactW)
+    {
+        // the cached plans (and captured graphs) decided per op between the exact-split and the fp32 kernel from the OLD
+        // model's list of weights that are not two-plane representable: decide again for this model
+        std::lock_guard<std::mutex> graphLock(g_graphMutex);
+        for (auto &kv : c->graphs)
+            (void)hipGraphExecDestroy(kv.second);
+        c->graphs.clear();
+        c->haveLastKey = false;
+        c->plans.clear();
+    }
     c->m = m; // kernels of earlier calls hold the old weight pointer by value: no synchronisation needed
     return DMX_OK;
 }
@@ -925,21 +953,6 @@ static int run_plan(dmx_ctx *c, int batch)
         }
         c->lastKey = key, c->haveLastKey = true;
     }
-    // plan lane (see "device lanes"): ordered behind the previous plan run of this device while a bf16x3 context exists
-    LstmLane *lane = lstm_lane(c->m->device);
-    // DMX_PLAN_LANE=0 (diagnostics only: tools/gpu_fft_erratum.sh, the opt-in half of the GPU stress test) switches the ordering off
-    static const bool planLaneOff = getenv("DMX_PLAN_LANE") && atoi(getenv("DMX_PLAN_LANE")) == 0;
-    const bool laneOn = lane && !planLaneOff && (lane->nSplit.load() > 0 || (lane->shared && lane->shared->nSplit.load() > 0));
-    std::unique_lock<std::mutex> planLock;
-    if (laneOn)
-    {
-        planLock = std::unique_lock<std::mutex>(lane->planMu);
-        if (!lane->planEv)
-            HIPCHK(hipEventCreateWithFlags(&lane->planEv, hipEventDisableTiming));
-        if (lane->planRecorded)
-            HIPCHK(hipStreamWaitEvent(c->stream, lane->planEv, 0));
-    }
-    SharedLaneGuard shared(lane ? lane->shared : nullptr, laneOn);
     if (exec)
     {
         std::lock_guard<std::mutex> graphLock(g_graphMutex);
@@ -949,13 +962,6 @@ static int run_plan(dmx_ctx *c, int batch)
         DMXCHK(enqueue_plan(c, p, two));
     c->lastBatch = batch;
     HIPCHK(hipGetLastError());
-    if (laneOn)
-    {
-        HIPCHK(hipEventRecord(lane->planEv, c->stream));
-        lane->planRecorded = true;
-    }
-    if (shared.held())
-        HIPCHK(hipStreamSynchronize(c->stream)); // another process may only start its plan run when this one has finished
     return DMX_OK;
 }
 

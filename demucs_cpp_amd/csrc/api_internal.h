@@ -100,7 +100,6 @@ struct dmx_ctx
         }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
-    bool inPlanLane = false; // a bf16x3 context: registered with its device's plan lane (api.cpp "device lanes")
     int gemm = 0;      // dmx::GemmMode of every plan of this context (DMX_GEMM_* of the C ABI), fixed at creation
     int graphMode = 1; // env DMX_GRAPH: 0 off, 1 (default) capture the two-stream plans of small batches into HIP graphs
     int fuseIstft = 1; // env DMX_FUSE_ISTFT=0: ISTFT and overlap-add as two kernels through the `frames` tensor (A/B)

@@ -1,0 +1,68 @@
+"""Rules on the SHIPPED machine code (no GPU needed: the gfx950 code objects are cut out of libdemucs_hip.so and disassembled).
+
+Rule 1 - no packed fp32 VALU arithmetic. On gfx950 `v_pk_{add,mul,fma}_f32` with the low lane reading the high half of src1
+(op_sel:[0,1,..]) returns wrong results in lanes 48-63 while another wave of the same CU executes 16-bit-input MFMAs
+(tools/micro/pk_f32_erratum.hip: 2-3 % of the results of such an instruction next to v_mfma_f32_16x16x32_bf16 / _f16, none next to
+fp32 MFMAs or VALU work; found in round 5 as the cause of the wrong STFT / ISTFT frames of DESIGN.md section 7). Every kernel of
+this library may share a CU with the exact-split kernels' bf16 MFMAs (another stream of the same context below 8 segments,
+another context, the other workgroup of the same kernel), so the library is built without the instruction class altogether
+(Makefile NOPK) and this test keeps it that way."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "demucs_cpp_amd", "lib", "libdemucs_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def code_objects(path):
+    """the gfx950 code objects of every clang offload bundle embedded in a host binary"""
+    data = open(path, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", data, p + 24)
+        off = p + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and sz > 0:
+                out.append(data[p + o:p + o + sz])
+    return out
+
+
+@pytest.fixture(scope="module")
+def disassembly(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    d = tmp_path_factory.mktemp("isa")
+    text = []
+    cos = code_objects(LIB)
+    assert len(cos) >= 10, "expected one code object per HIP translation unit"
+    for i, co in enumerate(cos):
+        f = d / f"co{i}.co"
+        f.write_bytes(co)
+        text.append(subprocess.run([OBJDUMP, "-d", str(f)], capture_output=True, text=True, check=True).stdout)
+    return "\n".join(text)
+
+
+def test_no_packed_fp32_arithmetic_in_the_shipped_kernels(disassembly):
+    bad = re.findall(r"^.*\bv_pk_(?:add|mul|fma)_f32\b.*$", disassembly, flags=re.M)
+    assert not bad, f"{len(bad)} packed fp32 VALU instructions in libdemucs_hip.so, e.g. {bad[0].strip()}"
+    # v_pk_mov_b32 moves halves with the same op_sel routing; the build leaves none either
+    assert not re.search(r"\bv_pk_mov_b32\b", disassembly)
+
+
+def test_the_disassembly_is_the_product(disassembly):
+    """sanity of the extraction: the kernels this library is about are in there, on the instructions DESIGN.md names"""
+    for needle in ("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x4_f32", "v_cvt_pk_bf16_f32", "igemm_split_lin_kernel", "stft_kernel",
+                   "attention_split_kernel", "lstm_kernel"):
+        assert needle in disassembly, needle

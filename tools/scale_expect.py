@@ -38,6 +38,34 @@ def load_line(path):
     return d
 
 
+def measured_points(scale):
+    """{n_gpus: value} from a SCALE record of ANY shape: the driver's file is walked for every object that carries both
+    `n_gpus` and `value` (bench.py's own line, wherever the driver nests it: `parsed`, `runs[i]`, `points[i]`, `n1` ...);
+    objects with `n` / `value` or `n_gpus` inside `parsed` are covered by the same walk."""
+    out = {}
+
+    def walk(o):
+        if isinstance(o, dict):
+            n = o.get("n_gpus", o.get("n"))
+            v = o.get("value")
+            if v is None and isinstance(o.get("parsed"), dict):
+                v = o["parsed"].get("value")
+            if isinstance(n, int) and isinstance(v, (int, float)) and v > 0:
+                out[int(n)] = float(v)
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+        elif isinstance(o, str) and o.lstrip().startswith("{") and '"n_gpus"' in o:
+            try:
+                walk(json.loads(o[o.index("{"):o.rindex("}") + 1]))  # a raw stdout tail holding the JSON line
+            except Exception:
+                pass
+    walk(scale)
+    return out
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
@@ -62,11 +90,8 @@ def main():
         hi = t1 / (t1 + extra)
         lo = hi * (0.98 if n > 1 else 1.0)
         line = f"  N={n}: value {n * v1 * lo:9.1f} .. {n * v1 * hi:9.1f}   efficiency {lo:.3f} .. {hi:.3f}"
-        if scale and not scale.get("skipped"):
-            meas = None
-            for rec in scale.get("runs", scale.get("points", [])) if isinstance(scale, dict) else []:
-                if int(rec.get("n_gpus", rec.get("n", -1))) == n:
-                    meas = rec.get("value") or (rec.get("parsed") or {}).get("value")
+        if scale is not None and not (isinstance(scale, dict) and scale.get("skipped")):
+            meas = measured_points(scale).get(n)
             if meas:
                 eff = float(meas) / (n * v1)
                 line += f"   measured {float(meas):9.1f} eff {eff:.3f} " + ("OK" if eff >= 0.95 or n == 1 else "BELOW 0.95: check gather overlap / NCCL_MAX_NCHANNELS")
