@@ -239,6 +239,8 @@ static bool validate_plan(const Plan &p, std::string &why)
         GemmArgs k{};
         k.pro = g.pro, k.epi = g.epi;
         k.N = g.N, k.S1 = g.S1, k.seg0 = g.seg0, k.M = (i64)g.B * g.P1 * g.P0, k.L0 = g.L0, k.Cin = g.Cin;
+        if (g.epi == EPI_KPL || g.epi == EPI_VT) // exist on the exact-split kernels only; get_plan has checked split_ok
+            continue;
         if (!al || (g.cfg == kDirectCfg ? launch_dgemm(k, nullptr, true) : launch_igemm(g.cfg, k, nullptr, true)) != 0)
         {
             why = "op " + op.name + (al ? ": no kernel instantiated for its (tile, prologue, epilogue)" : ": staging alignment contract violated");
@@ -256,7 +258,29 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     auto p = std::make_unique<Plan>();
     PlanOpts opts;
     opts.gemm = c->gemm;
+    // K / V projections write the attention kernel's bf16 operand planes (plan.cpp plane_linear; DMX_KV_PLANES=0: A/B). All or
+    // nothing: if any such op cannot take its exact-split kernel (weights not two-plane exact, kernels switched off) the
+    // plan is rebuilt in the fp32-K/V form.
+    const bool planesOff = getenv("DMX_KV_PLANES") && atoi(getenv("DMX_KV_PLANES")) == 0; // (read per plan: tests switch it)
+    static const bool attSplitOffEnv = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0;
+    opts.kvPlanes = c->gemm == DMX_GEMM_BF16X3 && !planesOff && !attSplitOffEnv && c->m->pm.arch != 3 ? 1 : 0;
     build_plan(c->m->pm, c->seg, batch, *p, opts);
+    if (opts.kvPlanes)
+    {
+        bool ok = true;
+        AttnArgs t{};
+        t.hs = c->m->pm.dim / 8;
+        ok = launch_attention_split(t, nullptr, true) == 0;
+        for (const Op &op : p->ops)
+            if (op.kind == OP_IGEMM && (op.g.epi == EPI_KPL || op.g.epi == EPI_VT) && !split_ok(c, op.g))
+                ok = false;
+        if (!ok)
+        {
+            opts.kvPlanes = 0;
+            p = std::make_unique<Plan>();
+            build_plan(c->m->pm, c->seg, batch, *p, opts);
+        }
+    }
     for (Op &op : p->ops)
     {
         if (op.kind == OP_IGEMM)
@@ -698,6 +722,8 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         k.res = a(g.res), k.scale = w(g.scale_w), k.epiStats = a(g.epiStats), k.epiW = w(g.epiW_w), k.epiB = w(g.epiB_w);
         k.rowstat = a(g.rowstat), k.NB = g.NB, k.table = w(g.table_w), k.tableScale = g.tableScale;
         k.Lout = g.Lout, k.Cout = g.Cout, k.trS = g.trS, k.trOff = g.trOff;
+        k.kvPl = g.kv >= 0 ? reinterpret_cast<unsigned short *>(A + g.kv) : nullptr;
+        k.kvPlane = (i64)g.B * g.kvT * g.kvH * g.kvHs, k.kvCol0 = g.kvCol0, k.kvT = g.kvT, k.kvH = g.kvH, k.kvHs = g.kvHs;
         k.M = (i64)g.B * g.P1 * g.P0;
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
@@ -709,6 +735,8 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
             if (launch_igemm_split(g.cfg, k, s) == 0)
                 break;
         }
+        if (g.epi == EPI_KPL || g.epi == EPI_VT) // (get_plan only keeps such ops when the split kernel takes them)
+            return fail(DMX_ERR_ARG, "internal error: K/V plane projection %s without its exact-split kernel", op.name.c_str());
         if ((g.cfg == kDirectCfg ? launch_dgemm(k, s) : launch_igemm(g.cfg, k, s)) != 0)
             return fail(DMX_ERR_ARG, "internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)", op.name.c_str(), g.cfg, g.pro,
                         g.epi);
@@ -743,10 +771,17 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_ATTENTION:
     {
         const Attention &t = op.at;
-        const AttnArgs k{a(t.q), a(t.k), a(t.v), a(t.o), t.ldq, t.ldk, t.ldv, t.ldo, t.qBatch, t.kBatch, t.vBatch,
-                         t.oBatch, t.B, t.Tq, t.Tk, t.H, t.hs, t.scale};
+        AttnArgs k{a(t.q), a(t.k), a(t.v), a(t.o), t.ldq, t.ldk, t.ldv, t.ldo, t.qBatch, t.kBatch, t.vBatch,
+                   t.oBatch, t.B, t.Tq, t.Tk, t.H, t.hs, t.scale};
+        k.kpl = t.kpl >= 0 ? reinterpret_cast<const unsigned short *>(A + t.kpl) : nullptr;
+        k.vt = t.vt >= 0 ? reinterpret_cast<const unsigned short *>(A + t.vt) : nullptr;
+        k.kvPlane = (i64)t.B * t.Tk * t.H * t.hs;
         if (!(t.split && launch_attention_split(k, s) == 0))
+        {
+            if (t.kpl >= 0)
+                return fail(DMX_ERR_ARG, "internal error: attention op %s reads operand planes but has no exact-split kernel", op.name.c_str());
             launch_attention(k, s);
+        }
         break;
     }
     case OP_ISTFT:
@@ -853,8 +888,15 @@ static int enqueue_plan(dmx_ctx *c, Plan *p, bool two)
 {
     if (!two)
     {
+        static const bool dbgSync = getenv("DMX_DEBUG_SYNC") && atoi(getenv("DMX_DEBUG_SYNC")) != 0; // diagnostics: name the op that faults
         for (const Op &op : p->ops)
+        {
+            if (dbgSync && op.kind != OP_TAP)
+                fprintf(stderr, "dmx op %s (kind %d)\n", op.name.c_str(), (int)op.kind);
             DMXCHK(launch_op(c, op, c->stream, p->zeroOff));
+            if (dbgSync)
+                HIPCHK(hipStreamSynchronize(c->stream));
+        }
         return DMX_OK;
     }
     // freq branch on `stream`, time branch on `stream2`, joined by the waits plan.cpp derived from
@@ -1268,6 +1310,8 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
         flops = 2.0 * M * g.N * g.K;
         double in = (double)g.B * g.L1 * g.L0 * g.Cin, w = (double)g.N * g.K, out = 0;
         if (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES)
+            out = M * g.N;
+        else if (g.epi == EPI_KPL || g.epi == EPI_VT) // (algorithmic bytes stay those of the fp32 result: SURVEY 8d prices the unfused form)
             out = M * g.N;
         else if (g.epi == EPI_GLU || g.epi == EPI_GN_GLU_SCALE_RES)
             out = M * g.N / 2;

@@ -26,18 +26,40 @@
 // for the thread -> (key quad, dim quad) map used below. 72 KB per workgroup: two workgroups per CU.
 // Staging splits happen in the staging threads (fp32 from global memory -> 3 bf16 planes); head dim 48 (htdemucs-6s) is
 // padded to 64 with zeros in Q and K (a half-empty second k-step costs what a full one costs on this pipe).
+//
+// PL = true (round 5): K and V arrive ALREADY split, as the bf16 planes the K / V projections' epilogues wrote (plan.h EPI_KPL /
+// EPI_VT: the same split3_pk of the same fp32 values, so the operand bits are those of the PL = false path), K row-major
+// [plane][token][D], V^T tile by tile in exactly the LDS image order. Both go global -> LDS directly (global_load_lds_dwordx4,
+// 1 KB per wave instruction, the XOR swizzle applied to the SOURCE slot): no staging registers, no split and no ds_write in
+// the tile loop - the K / V splits were 1.6 of the 16.7 ms this kernel took per 42-segment step (ablation, profiles/r05_*),
+// redone by every query tile. Whole 64-key tiles only (plan.cpp planes_ok), so no masked tile exists in this form.
 #include "attention_common.h"
 #include "igemm_common.h"
 #include <cstdlib>
 #include <type_traits>
 
+// Ablation mask for diagnostic builds (make variant1 NAME=x FILE=attention_split FLAGS=-DDMX_ATT_ABL=<bits>): results WRONG by
+// construction, 0 in the product.  1: K / V staging without the operand split (three planes = the truncated bits)
+// 2: P without the split   4: no softmax arithmetic
+#ifndef DMX_ATT_ABL
+#define DMX_ATT_ABL 0
+#endif
+
 namespace dmx
 {
+
+__device__ __forceinline__ void att_split3(float x0, float x1, unsigned &h1, unsigned &h2, unsigned &h3, bool ablate)
+{
+    if (ablate)
+        h1 = h2 = h3 = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    else
+        split3_pk(x0, x1, h1, h2, h3);
+}
 
 __device__ __forceinline__ int swzK(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int swzV(int dim) { return ((dim >> 1) & 1) | (((dim >> 3) & 1) << 1) | (((dim >> 2) & 1) << 2); }
 
-template <int HS, int QF>
+template <int HS, int QF, bool PL>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs p)
 {
     constexpr int DF = HS / 16;  // dim fragments of O
@@ -140,10 +162,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
                 continue;
             const int key = c / KSL, sl = c - key * KSL;
             unsigned h1[4], h2[4], h3[4];
-            split3_pk(kreg[i][0][0], kreg[i][0][1], h1[0], h2[0], h3[0]);
-            split3_pk(kreg[i][0][2], kreg[i][0][3], h1[1], h2[1], h3[1]);
-            split3_pk(kreg[i][1][0], kreg[i][1][1], h1[2], h2[2], h3[2]);
-            split3_pk(kreg[i][1][2], kreg[i][1][3], h1[3], h2[3], h3[3]);
+            att_split3(kreg[i][0][0], kreg[i][0][1], h1[0], h2[0], h3[0], (DMX_ATT_ABL & 1) != 0);
+            att_split3(kreg[i][0][2], kreg[i][0][3], h1[1], h2[1], h3[1], (DMX_ATT_ABL & 1) != 0);
+            att_split3(kreg[i][1][0], kreg[i][1][1], h1[2], h2[2], h3[2], (DMX_ATT_ABL & 1) != 0);
+            att_split3(kreg[i][1][2], kreg[i][1][3], h1[3], h2[3], h3[3], (DMX_ATT_ABL & 1) != 0);
             u32x4(*Kp)[KT][NS] = buf ? Kp1 : Kp0;
             const int sw = sl ^ swzK(key);
             Kp[0][key][sw] = u32x4{h1[0], h1[1], h1[2], h1[3]};
@@ -158,14 +180,52 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
         for (int c = 0; c < 4; ++c) // dim 4 vdq + c: keys 4 vkq4 .. +3
         {
             unsigned a1, a2, a3, b1, b2, b3;
-            split3_pk(vreg[0][c], vreg[1][c], a1, a2, a3);
-            split3_pk(vreg[2][c], vreg[3][c], b1, b2, b3);
+            att_split3(vreg[0][c], vreg[1][c], a1, a2, a3, (DMX_ATT_ABL & 1) != 0);
+            att_split3(vreg[2][c], vreg[3][c], b1, b2, b3, (DMX_ATT_ABL & 1) != 0);
             const int dim = 4 * vdq + c;
             const int sw = (4 * vs + vh4) ^ swzV(dim);
             *(reinterpret_cast<u32x2 *>(&Vp[0][dim][sw]) + vhalf) = u32x2{a1, b1};
             *(reinterpret_cast<u32x2 *>(&Vp[1][dim][sw]) + vhalf) = u32x2{a2, b2};
             *(reinterpret_cast<u32x2 *>(&Vp[2][dim][sw]) + vhalf) = u32x2{a3, b3};
         }
+    };
+
+    // ---- PL: direct global -> LDS staging of the pre-split planes. One wave instruction moves 1 KB = 8 image rows; lane l lands
+    // at (row 8 c + l / 8, slot position l % 8) and therefore FETCHES source slot (l % 8) ^ swizzle(row).
+    const int drow = lane >> 3, dpos = lane & 7;
+    const int D = p.H * HS;
+    const int wv = __builtin_amdgcn_readfirstlane(wave); // (uniform: the chunk tests below are scalar branches)
+    auto dma_k = [&](int t0, int buf) {
+        u32x4(*Kp)[KT][NS] = buf ? Kp1 : Kp0;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+            {
+                const int c = 2 * wv + i, key = 8 * c + drow;
+                const int src = dpos ^ swzK(key);
+                const i64 r = (i64)b * p.Tk + min(t0 + key, p.Tk - 1);
+                const unsigned short *g = p.kpl + (i64)pl * p.kvPlane + r * D + head * HS + 8 * src;
+                if (KSL == NS || src < KSL) // (HS = 48: the two padding slots of a row stay zero)
+                    load_to_lds_b128(reinterpret_cast<const float *>(g), reinterpret_cast<float4 *>(&Kp[pl][8 * c][0]));
+            }
+    };
+    auto dma_v = [&](int t) {
+        const int nt = p.Tk >> 6;
+        const i64 tile = ((i64)b * p.H + head) * nt + min(t, nt - 1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+            {
+                const int c = wv + 4 * i; // 8 (HS = 64) or 6 (HS = 48) chunks of 8 dims
+                if (c < HS / 8)
+                {
+                    const int dim = 8 * c + drow;
+                    const unsigned short *g = p.vt + (i64)pl * p.kvPlane + (tile * HS + dim) * 64 + 8 * (dpos ^ swzV(dim));
+                    load_to_lds_b128(reinterpret_cast<const float *>(g), reinterpret_cast<float4 *>(&Vp[pl][8 * c][0]));
+                }
+            }
     };
 
     f32x4 o[QF][DF];
@@ -224,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
             for (int f = 0; f < QF; ++f)
             {
                 unsigned h1[4], h2[4], h3[4];
-                split3_pk(sT[f][2 * s][0], sT[f][2 * s][1], h1[0], h2[0], h3[0]);
-                split3_pk(sT[f][2 * s][2], sT[f][2 * s][3], h1[1], h2[1], h3[1]);
-                split3_pk(sT[f][2 * s + 1][0], sT[f][2 * s + 1][1], h1[2], h2[2], h3[2]);
-                split3_pk(sT[f][2 * s + 1][2], sT[f][2 * s + 1][3], h1[3], h2[3], h3[3]);
+                att_split3(sT[f][2 * s][0], sT[f][2 * s][1], h1[0], h2[0], h3[0], (DMX_ATT_ABL & 2) != 0);
+                att_split3(sT[f][2 * s][2], sT[f][2 * s][3], h1[1], h2[1], h3[1], (DMX_ATT_ABL & 2) != 0);
+                att_split3(sT[f][2 * s + 1][0], sT[f][2 * s + 1][1], h1[2], h2[2], h3[2], (DMX_ATT_ABL & 2) != 0);
+                att_split3(sT[f][2 * s + 1][2], sT[f][2 * s + 1][3], h1[3], h2[3], h3[3], (DMX_ATT_ABL & 2) != 0);
                 pp[f][0] = __builtin_bit_cast(bf16x8, u32x4{h1[0], h1[1], h1[2], h1[3]});
                 pp[f][1] = __builtin_bit_cast(bf16x8, u32x4{h2[0], h2[1], h2[2], h2[3]});
                 pp[f][2] = __builtin_bit_cast(bf16x8, u32x4{h3[0], h3[1], h3[2], h3[3]});
@@ -258,6 +318,44 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
 
     const int nt = (p.Tk + KT - 1) / KT;
     const bool partial = (p.Tk % KT) != 0;
+    if constexpr (PL)
+    {
+        // prologue: K(0) -> Kp0; then per tile t (PAR = t & 1):
+        //   request V(t) -> V^T image (every wave is past P V of tile t-1: barrier X) and K(t+1) -> K buffer PAR ^ 1 (last read by
+        //   S(t-1)); S(t) from K buffer PAR; softmax; wait for this wave's V(t) pieces (the K(t+1) pieces may stay in flight);
+        //   barrier Z; O += V(t)^T P^T; wait for the K(t+1) pieces; barrier X.
+        dma_k(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto tilep = [&](int t, auto parTag) {
+            constexpr int PAR = decltype(parTag)::value;
+            dma_v(t);
+            dma_k((t + 1) * KT, PAR ^ 1); // beyond the end: a clamped re-read, never used
+            f32x4 sT[QF][4];
+            scores(PAR, sT);
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+            {
+                att_softmax_pre<DF, false, false>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, 0, 0.f);
+                att_softmax_post(sT[f], lrun[f], mcur[f]);
+            }
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // the six K(t+1) pieces were issued last: everything before them has landed
+            __syncthreads();
+            pvprod(sT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 1 < nt; t += 2)
+        {
+            tilep(t, std::integral_constant<int, 0>{});
+            tilep(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < nt)
+            tilep(t, std::integral_constant<int, 0>{});
+    }
+    else
+    {
     // ---- prologue: K(0) -> Kp0, K(1) and V(0) in the staging registers
     load_k(0);
     load_v(0);
@@ -281,8 +379,11 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
 #pragma unroll
         for (int f = 0; f < QF; ++f)
         {
-            att_softmax_pre<DF, MASK, false>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, 0, 0.f);
-            att_softmax_post(sT[f], lrun[f], mcur[f]);
+            if (!(DMX_ATT_ABL & 4))
+            {
+                att_softmax_pre<DF, MASK, false>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, 0, 0.f);
+                att_softmax_post(sT[f], lrun[f], mcur[f]);
+            }
         }
         __syncthreads();
         pvprod(sT);
@@ -310,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
         tile(t, even, std::true_type{});
     else
         tile(t, even, std::false_type{});
+    } // !PL
 
 #pragma unroll
     for (int f = 0; f < QF; ++f)
@@ -343,20 +445,30 @@ int launch_attention_split(const AttnArgs &a0, hipStream_t s, bool dry)
     a.nQt = (unsigned)(big ? (a.Tq + 127) / 128 : (a.Tq + 63) / 64);
     const unsigned nbh = (unsigned)(a.B * a.H);
     const dim3 grid(xcdMap ? 8u * ((nbh + 7u) / 8u) * a.nQt : nbh * a.nQt);
+    const bool planes = a.kpl && a.vt && a.Tk % 64 == 0;
+#define DMX_ATT_LAUNCH(HS_, QF_)                                                                            \
+    do                                                                                                      \
+    {                                                                                                       \
+        if (planes)                                                                                         \
+            hipLaunchKernelGGL((attention_split_kernel<HS_, QF_, true>), grid, dim3(256), 0, s, a);          \
+        else                                                                                                \
+            hipLaunchKernelGGL((attention_split_kernel<HS_, QF_, false>), grid, dim3(256), 0, s, a);         \
+    } while (0)
     if (big)
     {
         if (a.hs == 64)
-            hipLaunchKernelGGL((attention_split_kernel<64, 2>), grid, dim3(256), 0, s, a);
+            DMX_ATT_LAUNCH(64, 2);
         else
-            hipLaunchKernelGGL((attention_split_kernel<48, 2>), grid, dim3(256), 0, s, a);
+            DMX_ATT_LAUNCH(48, 2);
     }
     else
     {
         if (a.hs == 64)
-            hipLaunchKernelGGL((attention_split_kernel<64, 1>), grid, dim3(256), 0, s, a);
+            DMX_ATT_LAUNCH(64, 1);
         else
-            hipLaunchKernelGGL((attention_split_kernel<48, 1>), grid, dim3(256), 0, s, a);
+            DMX_ATT_LAUNCH(48, 1);
     }
+#undef DMX_ATT_LAUNCH
     return 0;
 }
 

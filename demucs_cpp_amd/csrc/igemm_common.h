@@ -385,6 +385,111 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int l15 = lane & 15, kq = lane >> 4;
+    if constexpr (EPI == EPI_VT)
+    {
+        // The caller issued its MFMAs the OTHER way round (activations as A, weights as B): the accumulator holds C, lane
+        // (l15, kq) owns channel n = 16 j + l15 and the 4 CONSECUTIVE tokens 16 i + 4 kq + {0..3} of row block i - one 8-byte piece
+        // (4 keys of one dim) of the attention kernel's V^T tile image (attention_split.hip): tile = 64 keys, 16-byte slot
+        // 4 s + h4 of a dim's row = keys 32 s + 4 h4 + {0..3} (first half) and 32 s + 16 + 4 h4 + {0..3} (second half): the two
+        // halves are the SAME lane's pieces of row blocks i and i + 1 (i even), so a wave tile of 32 rows stores whole slots.
+        // Tokens are rows m = b kvT + t with kvT a multiple of 64: the tokens of a 32-row block share b and the tile.
+        const int nt = p.kvT >> 6;
+        constexpr int IS = (WMF % 2 == 0) ? 2 : 1;
+#pragma unroll
+        for (int i = 0; i < WMF; i += IS)
+        {
+            const i64 m = m0 + wm * (WMF * 16) + i * 16 + 4 * kq; // first of this lane's four tokens of row block i
+            if (m >= p.M)
+                continue;
+            const unsigned b = (unsigned)m / (unsigned)p.kvT, t = (unsigned)m - b * (unsigned)p.kvT;
+            const unsigned tt = t & 63u, slot = 4u * (tt >> 5) + ((tt >> 2) & 3u), half = (tt >> 4) & 1u;
+#pragma unroll
+            for (int j = 0; j < WNF; ++j)
+            {
+                const int n = n0 + wn * (WNF * 16) + j * 16 + l15;
+                if (n >= p.N)
+                    continue;
+                const float bv = p.bias[n];
+                const unsigned head = (unsigned)n / (unsigned)p.kvHs, dim = (unsigned)n - head * (unsigned)p.kvHs;
+                unsigned short *dst = p.kvPl + ((((i64)b * p.kvH + head) * nt + (t >> 6)) * p.kvHs + dim) * 64 + slot * 8;
+                unsigned h1[2 * IS], h2[2 * IS], h3[2 * IS];
+#pragma unroll
+                for (int u = 0; u < IS; ++u)
+                {
+                    split3_pk(acc[i + u][j][0] + bv, acc[i + u][j][1] + bv, h1[2 * u], h2[2 * u], h3[2 * u]);
+                    split3_pk(acc[i + u][j][2] + bv, acc[i + u][j][3] + bv, h1[2 * u + 1], h2[2 * u + 1], h3[2 * u + 1]);
+                }
+                if constexpr (IS == 2)
+                {
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+                    *reinterpret_cast<u32x4 *>(dst + p.kvPlane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 2 * p.kvPlane) = u32x4{h3[0], h3[1], h3[2], h3[3]};
+                }
+                else
+                {
+                    *reinterpret_cast<u32x2 *>(dst + half * 4) = u32x2{h1[0], h1[1]};
+                    *reinterpret_cast<u32x2 *>(dst + half * 4 + p.kvPlane) = u32x2{h2[0], h2[1]};
+                    *reinterpret_cast<u32x2 *>(dst + half * 4 + 2 * p.kvPlane) = u32x2{h3[0], h3[1]};
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_KPL)
+    {
+        // v = acc + bias. Column fragments below kvCol0 (the q third of a self-attention projection): fp32 [row][n], as
+        // EPI_LINEAR. From kvCol0 on: the three bf16 planes of the exact split, [plane][row][n - kvCol0] - the K operand image
+        // of attention_split.hip. A lane owns 4 channels (8 bytes of a plane); fragments are taken in pairs and the 16-lane rows
+        // kq = 0 / 1 (2 / 3) exchange halves (v_permlane16_swap) so that a lane stores 8 consecutive channels = 16 bytes of ONE
+        // fragment: row kq even -> fragment j, channels 8 (kq >> 1) .. + 7; row kq odd -> fragment j + 1, same channels.
+        static_assert(WNF % 2 == 0, "fragment pairs");
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            const int rl = wm * (WMF * 16) + i * 16 + l15;
+            const i64 m = m0 + rl;
+            const bool rowOk = m < p.M;
+#pragma unroll
+            for (int j = 0; j < WNF; j += 2)
+            {
+                const int nb = n0 + wn * (WNF * 16) + j * 16; // first channel of the pair (a multiple of 32)
+                float4 v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const int n = nb + 16 * u + 4 * kq;
+                    const float4 bs = ld4z(p.bias + n, n < p.N, p.zero);
+                    v[u] = make_float4(acc[i][j + u][0] + bs.x, acc[i][j + u][1] + bs.y, acc[i][j + u][2] + bs.z, acc[i][j + u][3] + bs.w);
+                }
+                if (nb < p.kvCol0) // (uniform per fragment pair)
+                {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (rowOk && nb + 16 * u + 4 * kq < p.N)
+                            *reinterpret_cast<float4 *>(p.Y + m * p.ldy + nb + 16 * u + 4 * kq) = v[u];
+                    continue;
+                }
+                unsigned h[3][2][2]; // [plane][fragment of the pair][dword]
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    split3_pk(v[u].x, v[u].y, h[0][u][0], h[1][u][0], h[2][u][0]);
+                    split3_pk(v[u].z, v[u].w, h[0][u][1], h[1][u][1], h[2][u][1]);
+                }
+                const int nn = nb + 16 * (kq & 1) + 8 * (kq >> 1);
+                unsigned short *dst = p.kvPl + m * (i64)(p.kvH * p.kvHs) + (nn - p.kvCol0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                {
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(h[pl][0][0], h[pl][1][0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(h[pl][0][1], h[pl][1][1], false, false);
+                    if (rowOk && nn < p.N)
+                        *reinterpret_cast<u32x4 *>(dst + pl * p.kvPlane) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        }
+        return;
+    }
     const bool wantStats = p.rowstat != nullptr;
     const int colBase = n0 + wn * (WNF * 16) + 4 * kq;
     float4 biasv[WNF], scalev[WNF], gnWv[WNF], gnBv[WNF];
@@ -650,7 +755,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
     }
     } // groups of row blocks
     if (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_STATS_ONLY || EPI == EPI_STATS_FACT)
-        if (wantStats)
+        if (wantStats) // (EPI_KPL / EPI_VT ops carry no row statistics)
         {
             __syncthreads();
             for (int r = tid; r < BM; r += NT)
@@ -676,7 +781,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
 // "linear layer" addressing applies (StageWalk LIN): one contiguous run of K floats per row, K a multiple of the K-tile
 inline bool gemm_is_linear(const GemmArgs &a, int pro, int epi, int ktile)
 {
-    return pro == PRO_NONE && (epi == EPI_LINEAR || epi == EPI_SCALE_RES || epi == EPI_GLU) && a.S1 == 1 && a.pad0 == 0 &&
+    return pro == PRO_NONE && (epi == EPI_LINEAR || epi == EPI_SCALE_RES || epi == EPI_GLU || epi == EPI_KPL || epi == EPI_VT) && a.S1 == 1 && a.pad0 == 0 &&
            a.seg0 == a.K && a.K == a.Kp && a.K % ktile == 0 && a.Np % 4 == 0 &&
            (i64)(a.P0 - 1) * a.stride0 * a.Cin + a.seg0 <= (i64)a.L0 * a.Cin && a.P1 == a.L1 && a.stride1 == 1 && a.pad1 == 0;
 }

@@ -20,6 +20,7 @@
 // groups ({0-3,12-15,20-27}, ...) then hits 16 distinct 16-byte slots. Row decomposition, conv addressing, prologues,
 // epilogues, tile map and row statistics are igemm_common.h - one text with igemm.hip.
 #include "igemm_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -489,7 +490,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             for (int i = 0; i < WMF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][h * 4 + j] = DMX_SPLIT_MFMA(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
+                {
+                    // EPI_VT: the transposed product (activations as the matrix pipe's A operand): the accumulator holds C, a lane
+                    // owns 4 consecutive TOKENS of one channel - the V^T pieces of the attention kernel (igemm_common.h)
+                    if constexpr (EPI == EPI_VT)
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(aPl[PAR][i][plane], b[j], acc[i][h * 4 + j], 0, 0, 0);
+                    else
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
+                }
         };
         if (!(DMX_SPLIT_ABL & 256) || !inLoop2)
             read_half(0);
@@ -593,7 +601,20 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
     // (LIN also requires every staging offset to fit 32 bits: the kernel addresses a row as base + 32-bit byte offset)
     const bool lin = gemm_is_linear(a, PRO, EPI, 32) && ((i64)a.B * a.xBS + 64) * 4 < (1ll << 32) &&
                      ((i64)(a.Wb2 - a.Wb1) + (i64)a.Np * a.Kp + 64) * 2 < (1ll << 32);
-    if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU))
+    if constexpr (EPI == EPI_KPL || EPI == EPI_VT)
+    {
+        // the K / V plane projections exist on the linear-layer kernel only (plan.cpp plane_linear keeps them on 128- / 64-row
+        // tiles; the V^T form needs its transposed MFMAs)
+        if constexpr (PRO == PRO_NONE && WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
+            if (lin)
+            {
+                hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                return;
+            }
+        fprintf(stderr, "demucs_hip: internal error: a K/V plane projection cannot run on this tile (cfg with BM %d, linear addressing %d)\n", BM, (int)lin);
+        abort();
+    }
+    else if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU))
     {
         if (lin)
         {
@@ -615,7 +636,8 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
             return;
         }
     }
-    hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
+    if constexpr (EPI != EPI_KPL && EPI != EPI_VT)
+        hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 // The MFMA-bound tile families only (plan.h kTileCfgs): 0 / 7 / 15 (2x2 waves, 4 column fragments), 9 / 16 (2 column
@@ -640,6 +662,11 @@ int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
         DMX_CASE(7, 2, 2, 2, 4, PRO_NONE, EPI_SCALE_RES)
         DMX_CASE(7, 2, 2, 2, 4, PRO_NONE, EPI_GLU)
         DMX_CASE(7, 2, 2, 2, 4, PRO_NONE, EPI_TRCONV)
+        // K / V projections that write the attention kernel's operand planes (plan.cpp plane_linear)
+        DMX_CASE(0, 2, 2, 4, 4, PRO_NONE, EPI_KPL)
+        DMX_CASE(0, 2, 2, 4, 4, PRO_NONE, EPI_VT)
+        DMX_CASE(7, 2, 2, 2, 4, PRO_NONE, EPI_KPL)
+        DMX_CASE(7, 2, 2, 2, 4, PRO_NONE, EPI_VT)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_LINEAR)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_GLU)
         DMX_CASE(2, 4, 1, 2, 6, PRO_NONE, EPI_TRCONV)

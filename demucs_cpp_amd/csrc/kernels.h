@@ -56,6 +56,9 @@ struct GemmArgs
     float tableScale;
     int Lout, Cout;
     int trS, trOff; // EPI_TRCONV: output position j = trS*p0 + r - trOff (plan.h)
+    unsigned short *kvPl; // EPI_KPL / EPI_VT: three bf16 planes, kvPlane elements apart (plan.h IGemm::kv)
+    i64 kvPlane;
+    int kvCol0, kvT, kvH, kvHs;
     i64 M;
     const float *zero; // >= 16 B of zeros, 16-byte aligned: target of out-of-range staging loads
     unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
@@ -136,6 +139,9 @@ struct AttnArgs
     const float *decay;
     int ldd;
     i64 dB;
+    // bf16 operand planes written by the K / V projections (plan.h Attention::kpl / vt), or null
+    const unsigned short *kpl, *vt;
+    i64 kvPlane; // elements per plane = B * Tk * H * hs
 };
 
 void launch_attention(const AttnArgs &a, hipStream_t s);

@@ -202,6 +202,7 @@ struct Builder
         g.tableScale = 0.f;
         g.NB = 1;
         g.trS = 4, g.trOff = 2;
+        g.kv = -1;
         return g;
     }
     void finish(IGemm &g, bool paired)
@@ -485,6 +486,11 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
     const i64 aQKVf = b.alloc((i64)B * tokF * 3 * D), aQKVt = b.alloc((i64)B * tokT * 3 * D);
     const i64 aKVf = b.alloc((i64)B * tokT * 2 * D), aKVt = b.alloc((i64)B * tokF * 2 * D);
     const i64 aAttF = b.alloc((i64)B * tokF * D), aAttT = b.alloc((i64)B * tokT * D);
+    // bf16 operand planes of K and V^T per branch (plane_linear below): three planes of B x tokens x D elements = 1.5 floats each
+    const bool planesOn = opts.kvPlanes && opts.gemm == GEMM_BF16X3 && (D / 8 == 64 || D / 8 == 48) && D % 128 == 0;
+    const i64 planeFloats = ((i64)B * std::max(tokF, tokT) * D * 3 + 1) / 2;
+    const i64 aKplF = planesOn ? b.alloc(planeFloats) : -1, aVtF = planesOn ? b.alloc(planeFloats) : -1;
+    const i64 aKplT = planesOn ? b.alloc(planeFloats) : -1, aVtT = planesOn ? b.alloc(planeFloats) : -1;
     const i64 aHidF = b.alloc((i64)B * tokF * FF), aHidT = b.alloc((i64)B * tokT * FF);
     const i64 aStNf = b.alloc((i64)B * 4), aStNt = b.alloc((i64)B * 4);
     // decoders
@@ -607,7 +613,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         pl.ops.push_back(op);
     };
     auto attention = [&](const std::string &name, int stream, i64 q, int ldq, i64 qB, i64 k, i64 v, int ldkv, i64 kvB,
-                         i64 o, int Tq, int Tk) {
+                         i64 o, int Tq, int Tk, i64 kpl = -1, i64 vt = -1) {
         Op op;
         op.kind = OP_ATTENTION;
         op.stream = stream;
@@ -615,8 +621,31 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         int hs = D / 8;
         op.at = Attention{q, k, v, o, ldq, ldkv, ldkv, D, qB, kvB, kvB, (i64)Tq * D, B, Tq, Tk, 8, hs,
                           1.0f / std::sqrt((float)hs)};
+        op.at.kpl = kpl, op.at.vt = vt;
         pl.ops.push_back(op);
     };
+    // K / V projections that leave the attention kernel's bf16 operand planes (GEMM_BF16X3 plans, PlanOpts::kvPlanes): the
+    // key / value tokens of a layer must be whole 64-key tiles (full-size segments: 2688 and 1344), head dim 64 or 48. Such an op
+    // always runs on igemm_split_lin_kernel (128- or 64-row tiles, whatever the batch: the V^T form issues its MFMAs with the
+    // operands the other way round, which only that kernel implements - one kernel family per op keeps batch = singles bitwise)
+    auto planes_ok = [&](int tokSrc) { return planesOn && tokSrc % 64 == 0; };
+    auto plane_linear = [&](const std::string &name, int stream, i64 x, int rows, i64 w, i64 bias, int N, i64 y, int ldy, int epi, i64 kv,
+                            int kvCol0) {
+        IGemm g = b.base_gemm();
+        g.B = B, g.P1 = rows, g.P0 = 1;
+        g.x = x, g.L1 = rows, g.L0 = 1, g.Cin = D;
+        g.seg0 = D;
+        g.w_w = w, g.bias_w = bias, g.N = N;
+        g.epi = epi, g.act = 0;
+        g.y = y, g.ldy = ldy, g.yBatchStride = (i64)rows * ldy;
+        g.kv = kv, g.kvCol0 = kvCol0, g.kvT = rows, g.kvH = 8, g.kvHs = D / 8;
+        b.finish(g, false);
+        if (g.cfg != 0 && g.cfg != 7)
+            g.cfg = 7;
+        g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
+        b.push_gemm(name, stream, g);
+    };
+
 
     // channel upsamplers (4s) + norm_in + positional embeddings; model_inference.cpp:214-252,
     // crosstransformer.cpp:205-263
@@ -649,16 +678,24 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
             int stream;
             i64 x, n, n2, qkv, kv, att, hid, stn, rs;
             int tok, tokOther;
-            i64 xOther;
+            i64 xOther, kpl, vt;
         };
-        Br br[2] = {{pf, 0, aQf, aNf, aN2f, aQKVf, aKVf, aAttF, aHidF, aStNf, aRsF, tokF, tokT, aQt},
-                    {ptn, 1, aQt, aNt, aN2t, aQKVt, aKVt, aAttT, aHidT, aStNt, aRsTt, tokT, tokF, aQf}};
+        Br br[2] = {{pf, 0, aQf, aNf, aN2f, aQKVf, aKVf, aAttF, aHidF, aStNf, aRsF, tokF, tokT, aQt, aKplF, aVtF},
+                    {ptn, 1, aQt, aNt, aN2t, aQKVt, aKVt, aAttT, aHidT, aStNt, aRsTt, tokT, tokF, aQf, aKplT, aVtT}};
         // phase 1: norms + projections (cross layers read the OTHER branch before it is
         // updated: "old_x" of crosstransformer.cpp:286-295)
         for (auto &r : br)
         {
             layernorm(r.p + ".norm1", r.stream, r.x, r.n, r.tok, r.p + ".norm1.w", r.p + ".norm1.b", -1);
-            if (self)
+            if (self && planes_ok(r.tok))
+            {
+                // q (fp32, columns [0, D) of the [tok][3D] buffer) and the K planes in one launch, the V^T planes in a second
+                plane_linear(r.p + ".qk", r.stream, r.n, r.tok, b.W(r.p + ".in_proj.Wt"), b.W(r.p + ".in_proj.b"), 2 * D, r.qkv, 3 * D,
+                             EPI_KPL, r.kpl, D);
+                plane_linear(r.p + ".v", r.stream, r.n, r.tok, b.W(r.p + ".in_proj.Wt") + (i64)2 * D * D, b.W(r.p + ".in_proj.b") + 2 * D, D,
+                             r.qkv, 3 * D, EPI_VT, r.vt, 0);
+            }
+            else if (self)
                 linear(r.p + ".qkv", r.stream, r.n, r.tok, D, b.W(r.p + ".in_proj.Wt"), b.W(r.p + ".in_proj.b"), 3 * D,
                        r.qkv, 3 * D, EPI_LINEAR, 0, -1, -1, -1);
             else
@@ -666,8 +703,16 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
                 layernorm(r.p + ".norm2", r.stream, r.xOther, r.n2, r.tokOther, r.p + ".norm2.w", r.p + ".norm2.b", -1);
                 linear(r.p + ".q", r.stream, r.n, r.tok, D, b.W(r.p + ".in_proj.Wt"), b.W(r.p + ".in_proj.b"), D, r.qkv, D,
                        EPI_LINEAR, 0, -1, -1, -1);
-                linear(r.p + ".kv", r.stream, r.n2, r.tokOther, D, b.W(r.p + ".in_proj.Wt") + (i64)D * D,
-                       b.W(r.p + ".in_proj.b") + D, 2 * D, r.kv, 2 * D, EPI_LINEAR, 0, -1, -1, -1);
+                if (planes_ok(r.tokOther))
+                {
+                    plane_linear(r.p + ".k", r.stream, r.n2, r.tokOther, b.W(r.p + ".in_proj.Wt") + (i64)D * D, b.W(r.p + ".in_proj.b") + D, D,
+                                 r.kv, 2 * D, EPI_KPL, r.kpl, 0);
+                    plane_linear(r.p + ".v", r.stream, r.n2, r.tokOther, b.W(r.p + ".in_proj.Wt") + (i64)2 * D * D,
+                                 b.W(r.p + ".in_proj.b") + 2 * D, D, r.kv, 2 * D, EPI_VT, r.vt, 0);
+                }
+                else
+                    linear(r.p + ".kv", r.stream, r.n2, r.tokOther, D, b.W(r.p + ".in_proj.Wt") + (i64)D * D,
+                           b.W(r.p + ".in_proj.b") + D, 2 * D, r.kv, 2 * D, EPI_LINEAR, 0, -1, -1, -1);
             }
         }
         // phase 2: attention, out_proj, FFN, norm_out; layers.cpp:454-530
@@ -675,10 +720,10 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         {
             if (self)
                 attention(r.p + ".attn", r.stream, r.qkv, 3 * D, (i64)r.tok * 3 * D, r.qkv + D, r.qkv + 2 * D, 3 * D,
-                          (i64)r.tok * 3 * D, r.att, r.tok, r.tok);
+                          (i64)r.tok * 3 * D, r.att, r.tok, r.tok, planes_ok(r.tok) ? r.kpl : -1, planes_ok(r.tok) ? r.vt : -1);
             else
                 attention(r.p + ".attn", r.stream, r.qkv, D, (i64)r.tok * D, r.kv, r.kv + D, 2 * D, (i64)r.tokOther * 2 * D,
-                          r.att, r.tok, r.tokOther);
+                          r.att, r.tok, r.tokOther, planes_ok(r.tokOther) ? r.kpl : -1, planes_ok(r.tokOther) ? r.vt : -1);
             linear(r.p + ".out_proj", r.stream, r.att, r.tok, D, b.W(r.p + ".out_proj.Wt"), b.W(r.p + ".out_proj.b"), D, r.x,
                    D, EPI_SCALE_RES, 0, r.x, b.W(r.p + ".gamma_1"), -1);
             std::string n3 = self ? ".norm2" : ".norm3"; // crosstransformer.cpp:111-113
@@ -844,8 +889,10 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
             yext = (i64)(g.B - 1) * g.yBatchStride + (i64)g.P1 * g.Lout * g.ldy;
         else
             yext = (M - 1) * g.ldy + g.N;
-        if (g.epi != EPI_STATS_ONLY)
+        if (g.epi != EPI_STATS_ONLY && g.epi != EPI_VT && !(g.epi == EPI_KPL && g.kvCol0 == 0))
             Wr(g.y, yext);
+        if (g.kv >= 0) // three bf16 planes of B * kvT * kvH * kvHs elements = 1.5 floats per element
+            Wr(g.kv, ((i64)g.B * g.kvT * g.kvH * g.kvHs * 3 + 1) / 2);
         if (g.res >= 0)
             R(g.res, yext);
         if (g.epi == EPI_GN_GLU_SCALE_RES)
@@ -893,8 +940,16 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
     {
         const Attention &t = op.at;
         R(t.q, (i64)(t.B - 1) * t.qBatch + (i64)(t.Tq - 1) * t.ldq + (i64)t.H * t.hs);
-        R(t.k, (i64)(t.B - 1) * t.kBatch + (i64)(t.Tk - 1) * t.ldk + (i64)t.H * t.hs);
-        R(t.v, (i64)(t.B - 1) * t.vBatch + (i64)(t.Tk - 1) * t.ldv + (i64)t.H * t.hs);
+        if (t.kpl >= 0)
+        {
+            R(t.kpl, ((i64)t.B * t.Tk * t.H * t.hs * 3 + 1) / 2);
+            R(t.vt, ((i64)t.B * t.Tk * t.H * t.hs * 3 + 1) / 2);
+        }
+        else
+        {
+            R(t.k, (i64)(t.B - 1) * t.kBatch + (i64)(t.Tk - 1) * t.ldk + (i64)t.H * t.hs);
+            R(t.v, (i64)(t.B - 1) * t.vBatch + (i64)(t.Tk - 1) * t.ldv + (i64)t.H * t.hs);
+        }
         Wr(t.o, (i64)(t.B - 1) * t.oBatch + (i64)(t.Tq - 1) * t.ldo + (i64)t.H * t.hs);
         break;
     }

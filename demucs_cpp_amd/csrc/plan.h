@@ -64,6 +64,12 @@ enum Epilogue
                                // are the factor [L; u; v] (hid = Cout rows of L with L^T L = W^T W, u = W^T 1,
                                // v = W^T b; bias = [0.., sum b, sum b^2 / 2]), so with z = acc + bias:
                                //   sum_n y_n   = z[hid]          sum_n y_n^2 = sum_{k<hid} z[k]^2 + 2 z[hid+1]
+    // GEMM_BF16X3 plans with PlanOpts::kvPlanes (plan.cpp, transformer): the K and V projections leave their results as the bf16
+    // operand planes of the attention kernel instead of fp32 (attention_split.hip reads them straight into LDS):
+    EPI_KPL = 7,               // v = acc+bias; columns < kvCol0: store fp32 [row][n]; columns >= kvCol0: three bf16 planes
+                               // [plane][row][n - kvCol0] of the exact split v = v1 + v2 + v3 (igemm_common.h split3_pk)
+    EPI_VT = 8,                // v = acc+bias as three bf16 planes of V^T in the attention kernel's LDS tile order:
+                               // [plane][b][head][key tile][dim][64 keys, slot order] (attention_split.hip)
 };
 
 // Statistics records are 4 floats: {mean, scale, std, 0}; scale is rstd = 1/sqrt(var+eps)
@@ -112,6 +118,10 @@ struct IGemm
                               // (k8/s4 with the 2-sample crop: 4, 2; v3's uncropped k8/s4: 4, 0; k4/s2: 2, 0)
     int cfg;                  // tile configuration index (engine)
     int split;                // GEMM_BF16X3 contexts (api.cpp split_ok): run on the exact-split bf16 kernel (igemm_split.hip)
+    // EPI_KPL / EPI_VT: A (float offset) of three bf16 planes of B*kvT*(kvH*kvHs) elements each; rows are tokens (P1 = kvT,
+    // P0 = 1), kvT a multiple of 64; -1 otherwise
+    i64 kv;
+    int kvCol0, kvT, kvH, kvHs;
 };
 
 struct StatsReduce
@@ -164,6 +174,8 @@ struct Attention
     int B, Tq, Tk, H, hs;
     float scale; // 1/sqrt(hs)
     int split;   // GEMM_BF16X3 contexts (api.cpp): run on the exact-split bf16 kernel (attention_split.hip)
+    i64 kpl = -1, vt = -1; // A: bf16 operand planes of K ([3][B][Tk][H*hs]) and V^T ([3][B][H][Tk/64][hs][64]) written by the
+                           // projections (EPI_KPL / EPI_VT), or -1: the kernel splits fp32 k / v itself
 };
 
 struct Istft
@@ -342,6 +354,7 @@ enum GemmMode
 struct PlanOpts
 {
     int gemm = GEMM_F32;
+    int kvPlanes = 0; // GEMM_BF16X3 only: K / V projections write the attention kernel's bf16 operand planes (EPI_KPL / EPI_VT)
 };
 
 struct Plan

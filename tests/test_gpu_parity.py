@@ -332,6 +332,50 @@ def test_bench_multi_rank_control_flow_on_one_gpu(model, port):
     assert d["config"]["models"] == (4 if model == "ft" else 1)
 
 
+@pytest.mark.parametrize("ns", [4, 6])
+def test_kv_operand_planes_equal_the_fp32_kv_path(ns, dmx, tmp_models, monkeypatch, oracle_threads):
+    """GEMM_BF16X3 contexts: where the key / value tokens of a layer are whole 64-key tiles (here 128 freq and 64 time
+    tokens; the full segment: 2688 and 1344) the K / V projections write the attention kernel's bf16 operand planes
+    (plan.h EPI_KPL / EPI_VT; the V^T form issues its MFMAs transposed) and the attention kernel stages them global -> LDS
+    directly (attention_split.hip PL). The planes hold the same split3 of the same fp32 values, so the stems must equal
+    the DMX_KV_PLANES=0 form of the same context bit for bit; batching must not change a bit either; both forms against the
+    oracle at every tap. (f32 contexts never take the planes path: for them this is the usual parity run at this size.)"""
+    import torch
+    seg, B = 16384, 5
+    rng = np.random.default_rng(77)
+    mixes = (0.1 * rng.standard_normal((B, 2, seg))).astype(np.float32)
+    m = dmx.Model(tmp_models[ns])
+    om = orc.OracleModel(tmp_models[ns])
+    outs, classes = {}, {}
+    for planes in ("1", "0"):
+        monkeypatch.setenv("DMX_KV_PLANES", planes)
+        ctx = dmx.Context(m, seg, B)
+        errs, out, ref = pu.compare_segment(ctx, om, mixes[0])
+        bad = {k: v for k, v in errs.items() if not (v < TOL)}
+        assert not bad, (planes, bad)
+        d_mix = torch.from_numpy(np.ascontiguousarray(mixes.transpose(0, 2, 1))).cuda()
+        d_out = torch.zeros((B, ns, 2, seg), device="cuda")
+        torch.cuda.synchronize()
+        ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+        ctx.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[0], out)
+        for b in range(1, B):
+            assert np.array_equal(got[b], ctx.segment(mixes[b])), (planes, b)  # batch = singles, bitwise
+        outs[planes] = got
+        classes[planes] = {r[0]: r[1] for r in ctx.profile(B, 1)}
+        ctx.close()
+    names1, names0 = set(classes["1"]), set(classes["0"])
+    if dmx.gemm_mode_name == "bf16x3":
+        assert any(n.endswith(".qk") for n in names1) and any(n.endswith("layers.1.k") for n in names1) and any(n.endswith(".v") for n in names1)
+        assert not any(n.endswith(".qkv") or n.endswith(".kv") for n in names1)
+    else:
+        assert names1 == names0
+    assert any(n.endswith(".qkv") for n in names0) and any(n.endswith(".kv") for n in names0)
+    assert np.array_equal(outs["1"], outs["0"])
+    m.close(); om.close()
+
+
 def test_two_contexts_on_one_gpu_do_not_disturb_each_other(dmx, tmp_models):
     """Two contexts of one model driven from two host threads on ONE GPU, full-size segments, no ordering between them (round
     4 serialised them behind a 'plan lane' because single FFT frames came out wrong in 20-60 % of such runs; round 5 found the
