@@ -59,16 +59,20 @@ __device__ __forceinline__ float2 mulw16(const float2 v, const float c, const fl
     return make_float2(v.x * c - v.y * si, v.x * si + v.y * c);
 }
 
-// In-LDS Stockham radix-16 FFT of FFT_N = 16^3 complex points: 3 autosort stages (one barrier each), every
-// thread does ONE 16-point DFT per stage in registers (4 x 4 decomposition, constants w16^(c d)). Half the LDS
-// traffic and half the barriers of the 6-stage radix-4 form it replaces. Input: a[FSW(i)]; result: b[FSW(i)].
-// sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse. tw[k] = exp(-2 pi i k / 4096), k < 2048.
+// In-LDS Stockham radix-16 FFT of FFT_N = 16^3 complex points: 3 autosort stages, every thread does ONE 16-point DFT per
+// stage in registers (4 x 4 decomposition, constants w16^(c d)). Half the LDS traffic of the 6-stage radix-4 form it
+// replaced. IN PLACE since round 5: a stage reads its 16 inputs into registers, all threads meet at a barrier, then the
+// outputs go back into the same 32 KB image (the autosort permutation moves every element, hence the barrier between the
+// reads and the writes; a second one publishes the stage). One image instead of two: 32 KB per transform, so five
+// (STFT) / three (fused ISTFT, with its twiddle table) workgroups share a CU instead of two - the kernels are bound by
+// the latency of their barrier-separated stages, which more resident workgroups hide (stft 0.46 -> see DESIGN.md, same bits).
+// Input and result: a[FSW(i)]. sign = -1 forward (w = exp(-2 pi i p/n)), +1 inverse. tw[k] = exp(-2 pi i k / 4096), k < 2048.
 // Stage with stride s (= 16^st), sub-transform length n = N/s, m = n/16, p < m, q < s:
 //   y[q + s (16 p + k)] = w_n^(p k) * sum_j w16^(j k) x[q + s (p + j m)]
 template <int SIGN>
-__device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__restrict__ tw, int tid)
+__device__ __forceinline__ void fft4096(float2 *a, const float2 *__restrict__ tw, int tid)
 {
-    float2 *x = a, *y = b;
+    float2 *x = a, *y = a;
 #pragma unroll 1
     for (int st = 0; st < FFT_LOG; st += 4)
     {
@@ -99,6 +103,7 @@ __device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__re
         for (int d = 0; d < 4; ++d)
             dft4<SIGN>(v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3]);
         const int o = q + s * 16 * p;
+        __syncthreads(); // every thread holds its inputs: the image may be overwritten
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -112,9 +117,6 @@ __device__ __forceinline__ void fft4096(float2 *a, float2 *b, const float2 *__re
                 y[FSW(i)] = r;
             }
         __syncthreads();
-        float2 *t = x;
-        x = y;
-        y = t;
     }
 }
 
@@ -133,7 +135,6 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid)
 __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
 {
     __shared__ float2 bufA[FFT_N];
-    __shared__ float2 bufB[FFT_N];
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int t = blockIdx.x, b = blockIdx.y;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
         }
     }
     __syncthreads();
-    fft4096<-1>(bufA, bufB, tw, tid);
+    fft4096<-1>(bufA, tw, tid);
 
     // split the two real spectra, scale by 1/sqrt(N), write CaC (re0, im0, re1, im1)
     float4 *out = reinterpret_cast<float4 *>(p.x) + ((i64)b * p.T + t) * 2048;
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs p)
     const float sc = 1.0f / 64.0f;
     for (int k = tid; k < 2048; k += 256)
     {
-        const float2 zk = bufB[FSW(k)]; // 3 stages: the result is in the second buffer
-        const float2 zn = bufB[FSW((FFT_N - k) & (FFT_N - 1))];
+        const float2 zk = bufA[FSW(k)];
+        const float2 zn = bufA[FSW((FFT_N - k) & (FFT_N - 1))];
         // X0 = (Z[k] + conj(Z[N-k]))/2 ; X1 = -i (Z[k] - conj(Z[N-k]))/2
         const float re0 = 0.5f * (zk.x + zn.x) * sc, im0 = 0.5f * (zk.y - zn.y) * sc;
         const float re1 = 0.5f * (zk.y + zn.y) * sc, im1 = -0.5f * (zk.x - zn.x) * sc;
@@ -211,7 +212,6 @@ void launch_stft(const StftArgs &a, hipStream_t s)
 __global__ __launch_bounds__(256) void istft_kernel(const IstftArgs p)
 {
     __shared__ float2 bufA[FFT_N];
-    __shared__ float2 bufB[FFT_N];
     const int tid = threadIdx.x;
     const int t = blockIdx.x, src = blockIdx.y, b = blockIdx.z;
     const float2 *tw = reinterpret_cast<const float2 *>(p.twiddle);
@@ -239,12 +239,12 @@ __global__ __launch_bounds__(256) void istft_kernel(const IstftArgs p)
     if (tid == 0)
         bufA[FSW(2048)] = make_float2(0.f, 0.f);
     __syncthreads();
-    fft4096<+1>(bufA, bufB, tw, tid);
+    fft4096<+1>(bufA, tw, tid);
     float *f0 = p.frames + ((((i64)b * p.S + src) * 2 + 0) * p.T + t) * 4096;
     float *f1 = p.frames + ((((i64)b * p.S + src) * 2 + 1) * p.T + t) * 4096;
     for (int i = tid; i < FFT_N; i += 256)
     {
-        const float2 z = bufB[FSW(i)];
+        const float2 z = bufA[FSW(i)];
         const float w = p.window[i];
         f0[i] = z.x * w;
         f1[i] = z.y * w;
@@ -354,10 +354,13 @@ __device__ __forceinline__ void istft_ola_step(const IstftOlaArgs &p, float2 (&a
         acc[PH][jj] = make_float2(0.f, 0.f); // slot f & 3 now collects hop f + 4
 }
 
-__global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
+// workgroups per CU the fused kernel is compiled for: 2 (210 registers) or 3 (168 registers; its 48 KB of LDS allow three)
+#ifndef DMX_ISTFT_WGS
+#define DMX_ISTFT_WGS 2
+#endif
+__global__ __launch_bounds__(256, DMX_ISTFT_WGS) void istft_ola_kernel(const IstftOlaArgs p)
 {
     __shared__ float2 bufA[FFT_N];
-    __shared__ float2 bufB[FFT_N];
     __shared__ float2 twS[2048]; // twiddles in LDS: a chunk of ~30 frames amortises the 16 KB; the one-frame-per-workgroup
                                  // kernels above take them from L1/L2 (3 loads per butterfly and stage in the dependency chain)
     const int tid = threadIdx.x;
@@ -437,25 +440,25 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftOlaArgs p)
                 bufA[FSW(2048)] = make_float2(0.f, 0.f);
             fetch(f + 1);
             __syncthreads();
-            fft4096<+1>(bufA, bufB, twS, tid); // ends with a barrier: bufB holds the frame
+            fft4096<+1>(bufA, twS, tid); // ends with a barrier: bufA holds the frame
         }
         const bool emit = t >= t0; // halo frames only build up the ring
         switch (f & 3)
         {
         case 0:
-            istft_ola_step<0>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
+            istft_ola_step<0>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         case 1:
-            istft_ola_step<1>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
+            istft_ola_step<1>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         case 2:
-            istft_ola_step<2>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
+            istft_ola_step<2>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         default:
-            istft_ola_step<3>(p, acc, bufB, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
+            istft_ola_step<3>(p, acc, bufA, f, tid, add, emit, b, src, meanT, stdT, wreg, rdI);
             break;
         }
-        __syncthreads(); // bufB is rewritten by the next frame's transform
+        __syncthreads(); // the image is rewritten by the next frame's spectrum
     }
 }
 
@@ -463,7 +466,7 @@ void launch_istft_ola(const IstftOlaArgs &a0, hipStream_t s)
 {
     IstftOlaArgs a = a0;
     // Chunks per (batch item, source): every chunk recomputes a 3-frame halo and loads the twiddles (~2 frames' worth), so
-    // no shorter than 8 frames - and the workgroups run in ROUNDS of two per CU (80 KB of LDS each), all the same length:
+    // no shorter than 8 frames - and the workgroups run in ROUNDS of DMX_ISTFT_WGS per CU, all the same length:
     // the launch lasts rounds x (frames per chunk + 5). The first form asked for "about four workgroups per CU" and got
     // 1184 workgroups = 2.3 rounds at 42 segments: the third round ran a third full. Take the chunk count with the
     // shortest launch (42 x 4 sources: 3 chunks = 504 workgroups, one round, 1.39 -> 1.05 ms; chunk boundaries do not
@@ -474,7 +477,7 @@ void launch_istft_ola(const IstftOlaArgs &a0, hipStream_t s)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * (cus > 0 ? cus : 256);
+        slots = DMX_ISTFT_WGS * (cus > 0 ? cus : 256);
     }
     const int maxch = a.T / 8 > 0 ? a.T / 8 : 1;
     long best = -1;

@@ -82,10 +82,17 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     // SQ_LDS_BANK_CONFLICT = 17 % of the LDS cycles). BN a multiple of 64: chunk i = plane i & 1 of row
     // 64 (i >> 1) + 2 (tid >> 3) + ((tid >> 2) & 1) - a group writes two whole rows of one plane, 128 contiguous bytes.
     // Other widths (96) keep the row-per-8-lanes form.
+    // Widths that are a multiple of 32 but not of 64 (the 96-wide family; round 5): the same idea with the row pairs of both
+    // planes numbered through - 8-lane group g = tid / 8 + 32 i writes row pair g % (BN / 2) of plane g / (BN / 2) (round 4 kept
+    // the row-per-8-lanes form there: SQ_LDS_BANK_CONFLICT 14.8 % of the 128x96 class's LDS cycles). 48-wide tiles keep it.
     constexpr bool BCF = BN % 64 == 0;
-    const int bOct = BCF ? (tid & 3) : (slane & 3);
-    auto bRowOf = [&](int i) { return BCF ? 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1) : srow + i * RP; };
-    auto bPlaneOf = [&](int i) { return BCF ? (i & 1) : (slane >> 2); };
+    constexpr bool BCP = !BCF && BN % 32 == 0;
+    const int bOct = (BCF || BCP) ? (tid & 3) : (slane & 3);
+    auto bGrp = [&](int i) { return (tid >> 3) + 32 * i; };
+    auto bRowOf = [&](int i) {
+        return BCF ? 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1) : BCP ? 2 * (bGrp(i) % (BN / 2)) + ((tid >> 2) & 1) : srow + i * RP;
+    };
+    auto bPlaneOf = [&](int i) { return BCF ? (i & 1) : BCP ? bGrp(i) / (BN / 2) : (slane >> 2); };
     StageWalk<AR, BR, KT, PRO, LIN> w(p, slane);
     w.init(rowinfo_of, [&](int i) { return srow + i * RP; }, bRowOf, n0, BN);
 
@@ -327,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 // activation byte is fetched twice, and each element is still split exactly once.
 // The MFMA operands are the same 8-element groups in the same order as in the kernel above, so the results are the
 // same bits (the batch / shard invariance tests run small batches on the 2 x 2 kernels and large ones on this one).
-template <int WMF, int WNF, int EPI>
+// DEPTH = staging register sets = K-tiles a load is issued ahead of the iteration that splits / stores it (2: one iteration
+// of cover, the product; 3: two, DMX_LIN_DEPTH=3 - the experiment of DESIGN.md section 7 on whether the loop waits for L2).
+template <int WMF, int WNF, int EPI, int DEPTH = 2>
 __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs p)
 {
     constexpr int KT = 32;
@@ -378,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         }
     }
 
-    f32x4 aRaw[2][WMF][2];
-    u32x4 bReg[2][BR];
+    f32x4 aRaw[DEPTH][WMF][2];
+    u32x4 bReg[DEPTH][BR];
     bf16x8 aPl[2][WMF][3];
     bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
@@ -401,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             bOff[i] += KT * 2;
         }
     };
-    auto split_block = [&](auto setTag, int i) {
-        constexpr int SET = decltype(setTag)::value;
+    auto split_block = [&](auto setTag, auto dstTag, int i) {
+        constexpr int SET = decltype(setTag)::value, DST = decltype(dstTag)::value;
         const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
         unsigned h1[4], h2[4], h3[4];
         if (DMX_SPLIT_ABL & 1)
@@ -423,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         // (the planes are computed HERE, between the MFMA groups: without this the compiler sinks the split of the odd
         // tiles into the next iteration's head, in front of its first fragment reads)
         asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
-        aPl[SET][i][0] = __builtin_bit_cast(bf16x8, q1);
-        aPl[SET][i][1] = __builtin_bit_cast(bf16x8, q2);
-        aPl[SET][i][2] = __builtin_bit_cast(bf16x8, q3);
+        aPl[DST][i][0] = __builtin_bit_cast(bf16x8, q1);
+        aPl[DST][i][1] = __builtin_bit_cast(bf16x8, q2);
+        aPl[DST][i][2] = __builtin_bit_cast(bf16x8, q3);
     };
     auto store_B = [&](auto setTag, int buf, int b0, int b1e) {
         constexpr int SET = decltype(setTag)::value;
@@ -458,23 +467,29 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     // requested a whole iteration earlier) and writes that tile's weight chunks into the other image. One barrier per tile.
     const std::integral_constant<int, 0> set0{};
     const std::integral_constant<int, 1> set1{};
+    const std::integral_constant<int, 2> set2{};
     const int nk = (p.Kp + 31) >> 5;
     issue_loads(set0);
     issue_loads(set1);
+    if constexpr (DEPTH == 3)
+        issue_loads(set2);
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
-        split_block(set0, i);
+        split_block(set0, set0, i);
     store_B(set0, 0, 0, BR);
     __syncthreads();
     const int fslot = kq ^ swz(l15);
     constexpr int NH = WNF / 4; // column fragments are processed four at a time
     bf16x8 b1[NH][4], b2[NH][4];
     bool inLoop2 = false; // (ablation 256: fragments are read in the first iteration only)
-    auto iteration = [&](auto parTag) {
-        constexpr int PAR = decltype(parTag)::value;
+    // PAR = kt & 1: the weight image and activation planes of tile kt; SET = kt % DEPTH: the register set that held tile kt
+    // (split / stored during iteration kt - 1), free for tile kt + DEPTH; tile kt + 1 waits in set (kt + 1) % DEPTH
+    auto iteration = [&](auto parTag, auto setTag) {
+        constexpr int PAR = decltype(parTag)::value, SET = decltype(setTag)::value;
         const std::integral_constant<int, PAR ^ 1> other{};
+        const std::integral_constant<int, (SET + 1) % DEPTH> nextSet{};
         u32x4(*Bp)[BN][4] = PAR ? Bp1 : Bp0;
-        issue_loads(parTag); // tile kt + 2
+        issue_loads(setTag); // tile kt + DEPTH
         auto read_half = [&](int h) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -513,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
                 if ((i * NH) / WMF == h)
-                    split_block(other, i);
-            store_B(other, PAR ^ 1, h * BR / NH, (h + 1) * BR / NH);
+                    split_block(nextSet, other, i);
+            store_B(nextSet, PAR ^ 1, h * BR / NH, (h + 1) * BR / NH);
             term(h, b2[h], 0);
             term(h, b1[h], 1);
             term(h, b1[h], 0);
@@ -528,11 +543,31 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 #ifdef DMX_TIMING
     tstamp[1] = wall_clock64();
 #endif
-    for (int kt = 0; kt < nk; kt += 2)
+    if constexpr (DEPTH == 2)
     {
-        iteration(set0);
-        if (kt + 1 < nk)
-            iteration(set1);
+        for (int kt = 0; kt < nk; kt += 2)
+        {
+            iteration(set0, set0);
+            if (kt + 1 < nk)
+                iteration(set1, set1);
+        }
+    }
+    else
+    {
+        for (int kt = 0; kt < nk; kt += 6) // parity and register set have periods 2 and 3
+        {
+            iteration(set0, set0);
+            if (kt + 1 < nk)
+                iteration(set1, set1);
+            if (kt + 2 < nk)
+                iteration(set0, set2);
+            if (kt + 3 < nk)
+                iteration(set1, set0);
+            if (kt + 4 < nk)
+                iteration(set0, set1);
+            if (kt + 5 < nk)
+                iteration(set1, set2);
+        }
     }
     __syncthreads(); // (rsum aliases the weight image)
 #ifdef DMX_TIMING
@@ -626,9 +661,13 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
             if constexpr (WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
             {
                 static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+                static const int depth = [] { const char *e = getenv("DMX_LIN_DEPTH"); return e ? atoi(e) : 2; }();
                 if (mode == 1)
                 {
-                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                    if (depth == 3)
+                        hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 3>), dim3(blocks), dim3(256), 0, s, a);
+                    else
+                        hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                     return;
                 }
             }

@@ -312,6 +312,21 @@ int main()
         run<2, 16, 6, 1, 2, 8, 1, 0, 0, 12>("fp16 terms again", sink, src, win, cus);
         run<0, 0, 0, 0, 2, 0, 0, 0, 0, 12>("48 MFMAs only", sink, src, win, cus);
     }
+    if (set == 8)
+    {
+        // does it matter WHERE the staged bytes come from? the linear-layer loop with its 8 loads per lane and K-tile served by the
+        // CU's own L1 (16 KB window: every workgroup reads the same lines), by L2 (64 KB .. 1 MB), by the Infinity Cache (16 MB+)
+        run<0, 0, 0, 0, 2>("warm-up", sink, src, (size_t)16 << 20, cus);
+        for (size_t win : {(size_t)16 << 10, (size_t)64 << 10, (size_t)1 << 20, (size_t)16 << 20, (size_t)256 << 20})
+        {
+            char tag[96];
+            snprintf(tag, sizeof tag, "LIN kernel (16 reads, 4 writes, 8 loads), window %zu KB", win >> 10);
+            run<1, 16, 8, 1, 2, 4, 1>(tag, sink, src, win, cus);
+            snprintf(tag, sizeof tag, "the same with 4 loads, window %zu KB", win >> 10);
+            run<1, 16, 4, 1, 2, 4, 1>(tag, sink, src, win, cus);
+        }
+        run<1, 16, 0, 1, 2, 4, 1>("the same with no loads", sink, src, (size_t)16 << 20, cus);
+    }
     if (set == 7)
     {
         // v_mfma_f32_16x16x32_f16 against ..._bf16: the same pipe rate? (random bit patterns as operands either way)
