@@ -334,9 +334,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 // activation byte is fetched twice, and each element is still split exactly once.
 // The MFMA operands are the same 8-element groups in the same order as in the kernel above, so the results are the
 // same bits (the batch / shard invariance tests run small batches on the 2 x 2 kernels and large ones on this one).
-// DEPTH = staging register sets = K-tiles a load is issued ahead of the iteration that splits / stores it (2: one iteration
-// of cover, the product; 3: two, DMX_LIN_DEPTH=3 - the experiment of DESIGN.md section 7 on whether the loop waits for L2).
-template <int WMF, int WNF, int EPI, int DEPTH = 2>
+// (Two experiments on this kernel were measured in round 5 and removed again - three staging register sets, persistent
+// workgroups with cross-tile prefetch: profiles/r05_experiments_split_gemm.md.)
+template <int WMF, int WNF, int EPI>
 __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs p)
 {
     constexpr int KT = 32;
@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         }
     }
 
-    f32x4 aRaw[DEPTH][WMF][2];
-    u32x4 bReg[DEPTH][BR];
+    f32x4 aRaw[2][WMF][2];
+    u32x4 bReg[2][BR];
     bf16x8 aPl[2][WMF][3];
     bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
@@ -467,12 +467,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     // requested a whole iteration earlier) and writes that tile's weight chunks into the other image. One barrier per tile.
     const std::integral_constant<int, 0> set0{};
     const std::integral_constant<int, 1> set1{};
-    const std::integral_constant<int, 2> set2{};
     const int nk = (p.Kp + 31) >> 5;
     issue_loads(set0);
     issue_loads(set1);
-    if constexpr (DEPTH == 3)
-        issue_loads(set2);
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
         split_block(set0, set0, i);
@@ -482,14 +479,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     constexpr int NH = WNF / 4; // column fragments are processed four at a time
     bf16x8 b1[NH][4], b2[NH][4];
     bool inLoop2 = false; // (ablation 256: fragments are read in the first iteration only)
-    // PAR = kt & 1: the weight image and activation planes of tile kt; SET = kt % DEPTH: the register set that held tile kt
-    // (split / stored during iteration kt - 1), free for tile kt + DEPTH; tile kt + 1 waits in set (kt + 1) % DEPTH
-    auto iteration = [&](auto parTag, auto setTag) {
-        constexpr int PAR = decltype(parTag)::value, SET = decltype(setTag)::value;
+    // PAR = kt & 1: the weight image, activation planes and staging register set of tile kt
+    auto iteration = [&](auto parTag) {
+        constexpr int PAR = decltype(parTag)::value;
         const std::integral_constant<int, PAR ^ 1> other{};
-        const std::integral_constant<int, (SET + 1) % DEPTH> nextSet{};
+        const std::integral_constant<int, PAR ^ 1> nextSet{};
         u32x4(*Bp)[BN][4] = PAR ? Bp1 : Bp0;
-        issue_loads(setTag); // tile kt + DEPTH
+        issue_loads(parTag); // tile kt + 2
         auto read_half = [&](int h) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -543,31 +539,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 #ifdef DMX_TIMING
     tstamp[1] = wall_clock64();
 #endif
-    if constexpr (DEPTH == 2)
+    for (int kt = 0; kt < nk; kt += 2)
     {
-        for (int kt = 0; kt < nk; kt += 2)
-        {
-            iteration(set0, set0);
-            if (kt + 1 < nk)
-                iteration(set1, set1);
-        }
-    }
-    else
-    {
-        for (int kt = 0; kt < nk; kt += 6) // parity and register set have periods 2 and 3
-        {
-            iteration(set0, set0);
-            if (kt + 1 < nk)
-                iteration(set1, set1);
-            if (kt + 2 < nk)
-                iteration(set0, set2);
-            if (kt + 3 < nk)
-                iteration(set1, set0);
-            if (kt + 4 < nk)
-                iteration(set0, set1);
-            if (kt + 5 < nk)
-                iteration(set1, set2);
-        }
+        iteration(set0);
+        if (kt + 1 < nk)
+            iteration(set1);
     }
     __syncthreads(); // (rsum aliases the weight image)
 #ifdef DMX_TIMING
@@ -602,208 +578,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         d[7] = blockIdx.x;
     }
 #endif
-}
-
-// ---- the same kernel as a PERSISTENT workgroup (round 5) ----------------------------------------------------------------
-// One workgroup per resident slot (2 per CU) walks the tiles b, b + G, b + 2 G, ... of the launch (G = grid size, a multiple
-// of 8: a workgroup keeps its XCD and the tiles it takes are the ones the dispatcher would have handed to its slot). The K
-// pipeline never drains between tiles: in the last two iterations of a tile the staging loads already fetch the FIRST two
-// K-tiles of the next tile (the address registers are switched to the next tile's rows and weight columns two iterations
-// before the end), the last iteration splits / stores the next tile's K-tile 0 like any "tile kt + 1", and the epilogue
-// of this tile runs with the next tile's operands in flight. What the one-tile kernel pays per tile - row decomposition,
-// first loads at full L2 latency, first split, a barrier: 2.8 us of a 34 us K = 512 tile (tools/gpu_wg_timeline.py) - is
-// paid once per workgroup. Same tile map, same MFMA order per tile: the bits are those of the one-tile kernel (GPU test).
-// Needs an even number of K-tiles (the image parity of the next tile's first K-tile is fixed at 0).
-template <int WMF, int WNF, int EPI>
-__global__ __launch_bounds__(256, 2) void igemm_split_linp_kernel(const GemmArgs p)
-{
-    constexpr int KT = 32;
-    constexpr int BM = 4 * WMF * 16, BN = WNF * 16;
-    constexpr int BR = BN / 32;
-    static_assert(BN % 64 == 0, "two rows of one plane per 8-lane store group");
-    __shared__ u32x4 Bp0[2][BN][4], Bp1[2][BN][4]; // [plane][column][octet slot]
-    __shared__ float2 rsumS[BM][2];                // row statistics scratch of the epilogue (not aliased: the images stay live)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const unsigned nV = 8u * ((p.tilesM + 7u) / 8u) * p.tilesN; // virtual workgroup ids of the one-tile launch
-    auto tile_of_v = [&](unsigned vb, unsigned &tileM, unsigned &tileN) -> bool {
-        const unsigned xcd = vb & 7u, j = vb >> 3;
-        const unsigned mi = j / p.tilesN;
-        tileN = j - mi * p.tilesN;
-        tileM = mi * 8u + xcd;
-        return tileM < p.tilesM;
-    };
-    const int bOct = tid & 3;
-    auto bRowOf = [&](int i) { return 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1); };
-    const i64 rowLen = (i64)p.L0 * p.Cin;
-    const unsigned planeDelta = (unsigned)(p.Wb2 - p.Wb1);
-    auto offsets_of = [&](unsigned tileM, unsigned tileN, unsigned (&aO)[WMF], unsigned (&bO)[BR]) {
-        const i64 m0 = (i64)tileM * BM;
-        const int n0 = (int)tileN * BN;
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-        {
-            const i64 m = min(m0 + wave * (WMF * 16) + i * 16 + l15, p.M - 1);
-            const int4 ri = row_info(p, m);
-            aO[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-        {
-            const int n = min(n0 + bRowOf(i), p.Np - 1);
-            bO[i] = ((unsigned)n * (unsigned)p.Kp + (unsigned)bOct * 8u + ((i & 1) ? planeDelta : 0u)) * 2u;
-        }
-    };
-    unsigned vb = blockIdx.x, tM = 0, tN = 0;
-    while (vb < nV && !tile_of_v(vb, tM, tN))
-        vb += gridDim.x;
-    if (vb >= nV)
-        return; // (whole workgroup, before any barrier)
-    unsigned aOff[WMF], bOff[BR];
-    offsets_of(tM, tN, aOff, bOff);
-
-    f32x4 aRaw[2][WMF][2];
-    u32x4 bReg[2][BR];
-    bf16x8 aPl[2][WMF][3];
-    auto issue_loads = [&](auto setTag) {
-        constexpr int SET = decltype(setTag)::value;
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-        {
-            const char *src = reinterpret_cast<const char *>(p.X) + aOff[i];
-            aRaw[SET][i][0] = *reinterpret_cast<const f32x4 *>(src);
-            aRaw[SET][i][1] = *reinterpret_cast<const f32x4 *>(src + 16);
-            aOff[i] += KT * 4;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-        {
-            bReg[SET][i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.Wb1) + bOff[i]);
-            bOff[i] += KT * 2;
-        }
-    };
-    auto split_block = [&](auto setTag, int i) {
-        constexpr int SET = decltype(setTag)::value;
-        const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
-        unsigned h1[4], h2[4], h3[4];
-        split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
-        split3_pk(lo[2], lo[3], h1[1], h2[1], h3[1]);
-        split3_pk(hi[0], hi[1], h1[2], h2[2], h3[2]);
-        split3_pk(hi[2], hi[3], h1[3], h2[3], h3[3]);
-        u32x4 q1{h1[0], h1[1], h1[2], h1[3]}, q2{h2[0], h2[1], h2[2], h2[3]}, q3{h3[0], h3[1], h3[2], h3[3]};
-        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3)); // (computed HERE, between the MFMA groups: igemm_split_lin_kernel)
-        aPl[SET][i][0] = __builtin_bit_cast(bf16x8, q1);
-        aPl[SET][i][1] = __builtin_bit_cast(bf16x8, q2);
-        aPl[SET][i][2] = __builtin_bit_cast(bf16x8, q3);
-    };
-    auto store_B = [&](auto setTag, int buf, int b0, int b1e) {
-        constexpr int SET = decltype(setTag)::value;
-        u32x4(*Bp)[BN][4] = buf ? Bp1 : Bp0;
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-        {
-            if (i < b0 || i >= b1e)
-                continue;
-            const int row = bRowOf(i);
-            Bp[i & 1][row][bOct ^ swz(row)] = bReg[SET][i];
-        }
-    };
-
-    f32x4 acc[WMF][WNF];
-    const std::integral_constant<int, 0> set0{};
-    const std::integral_constant<int, 1> set1{};
-    const int nk = (p.Kp + 31) >> 5; // even (launcher)
-    issue_loads(set0);
-    issue_loads(set1);
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-        split_block(set0, i);
-    store_B(set0, 0, 0, BR);
-    __syncthreads();
-    const int fslot = kq ^ swz(l15);
-    constexpr int NH = WNF / 4;
-    bf16x8 b1[NH][4], b2[NH][4];
-    auto iteration = [&](auto parTag) {
-        constexpr int PAR = decltype(parTag)::value;
-        const std::integral_constant<int, PAR ^ 1> other{};
-        u32x4(*Bp)[BN][4] = PAR ? Bp1 : Bp0;
-        issue_loads(parTag); // K-tile kt + 2 of this tile - or, in a tile's last two iterations, K-tile 0 / 1 of the next tile
-        auto read_half = [&](int h) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                const int r = (h * 4 + j) * 16 + l15;
-                b1[h][j] = __builtin_bit_cast(bf16x8, Bp[0][r][fslot]);
-                b2[h][j] = __builtin_bit_cast(bf16x8, Bp[1][r][fslot]);
-            }
-        };
-        auto term = [&](int h, bf16x8(&b)[4], int plane) {
-#pragma unroll
-            for (int i = 0; i < WMF; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                {
-                    if constexpr (EPI == EPI_VT)
-                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aPl[PAR][i][plane], b[j], acc[i][h * 4 + j], 0, 0, 0);
-                    else
-                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
-                }
-        };
-        read_half(0);
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-        {
-            term(h, b1[h], 2); // smallest terms first: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (igemm_split_kernel)
-            if (h + 1 < NH)
-                read_half(h + 1);
-            term(h, b2[h], 1);
-#pragma unroll
-            for (int i = 0; i < WMF; ++i)
-                if ((i * NH) / WMF == h)
-                    split_block(other, i);
-            store_B(other, PAR ^ 1, h * BR / NH, (h + 1) * BR / NH);
-            term(h, b2[h], 0);
-            term(h, b1[h], 1);
-            term(h, b1[h], 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    };
-    for (;;)
-    {
-        // the tile after this one (its staging addresses are needed two iterations before this tile ends)
-        unsigned vbN = vb + gridDim.x, tMN = 0, tNN = 0;
-        bool haveNext = false;
-        while (vbN < nV)
-        {
-            if (tile_of_v(vbN, tMN, tNN))
-            {
-                haveNext = true;
-                break;
-            }
-            vbN += gridDim.x;
-        }
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; kt += 2)
-        {
-            if (kt == nk - 2 && haveNext)
-                offsets_of(tMN, tNN, aOff, bOff); // (derived here, not kept across the loop: the kernel sits at the register limit)
-            iteration(set0);
-            iteration(set1);
-        }
-        const i64 m0 = (i64)tM * BM;
-        const int n0 = (int)tN * BN;
-        auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
-        igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsumS, m0, n0, tN, wave, 0, BM);
-        if (!haveNext)
-            break;
-        vb = vbN, tM = tMN, tN = tNN;
-    }
 }
 
 // the kernels' activation split on an array (dmx_debug_split_activations: unit test of the split itself)
@@ -845,15 +619,7 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
         if constexpr (PRO == PRO_NONE && WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
             if (lin)
             {
-                static const int persist = [] { const char *e = getenv("DMX_LIN_PERSIST"); return e ? atoi(e) : 1; }();
-                int dev = 0, cus = 256;
-                if (hipGetDevice(&dev) == hipSuccess)
-                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                const unsigned slots = 2u * (unsigned)(cus > 0 ? cus : 256);
-                if (persist && ((a.Kp + 31) >> 5) % 2 == 0 && blocks >= 2 * slots && slots % 8 == 0)
-                    hipLaunchKernelGGL((igemm_split_linp_kernel<MF / 2, 8, EPI>), dim3(slots), dim3(256), 0, s, a);
-                else
-                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                 return;
             }
         fprintf(stderr, "demucs_hip: internal error: a K/V plane projection cannot run on this tile (cfg with BM %d, linear addressing %d)\n", BM, (int)lin);
@@ -871,26 +637,9 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
             if constexpr (WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
             {
                 static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
-                static const int depth = [] { const char *e = getenv("DMX_LIN_DEPTH"); return e ? atoi(e) : 2; }();
-                // persistent form (igemm_split_linp_kernel): worth it when a slot runs several tiles; DMX_LIN_PERSIST=0: A/B
-                static const int persist = [] { const char *e = getenv("DMX_LIN_PERSIST"); return e ? atoi(e) : 1; }();
-                static const unsigned slots = [] {
-                    int dev = 0, cus = 256;
-                    if (hipGetDevice(&dev) == hipSuccess)
-                        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                    return 2u * (unsigned)(cus > 0 ? cus : 256);
-                }();
-                if (mode == 1 && persist && depth == 2 && ((a.Kp + 31) >> 5) % 2 == 0 && blocks >= 2 * slots && slots % 8 == 0)
-                {
-                    hipLaunchKernelGGL((igemm_split_linp_kernel<MF / 2, 8, EPI>), dim3(slots), dim3(256), 0, s, a);
-                    return;
-                }
                 if (mode == 1)
                 {
-                    if (depth == 3)
-                        hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 3>), dim3(blocks), dim3(256), 0, s, a);
-                    else
-                        hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                     return;
                 }
             }
