@@ -85,7 +85,7 @@ extern "C" int dmx_default_gemm(void)
     if (g < 0)
     {
         // default since round 4: the exact operand-split path (every -m gpu parity test runs in both modes; DESIGN.md
-        // section 7.2); DMX_GEMM=f32 selects the fp32 MFMA kernels
+        // section 2.5); DMX_GEMM=f32 selects the fp32 MFMA kernels
         const char *e = getenv("DMX_GEMM");
         g = e && !strcmp(e, "f32") ? DMX_GEMM_F32 : DMX_GEMM_BF16X3;
         if (e && *e && strcmp(e, "f32") && strcmp(e, "bf16x3")) // a typo must not silently select the other arithmetic

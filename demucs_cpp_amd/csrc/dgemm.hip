@@ -643,7 +643,7 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
         {
             // chunk width: 192 columns keep 12 x K weights in registers (268 / 351 VGPRs: one wave per SIMD) and read the hidden
             // row N / 192 times; 96 columns (6 fragments, ~130 VGPRs: three to four waves per SIMD) read it N / 96 times.
-            // DMX_K3_CHUNK=96|192 for A/B runs; the default is the measured winner
+            // DMX_K3_CHUNK=96|192 for A/B runs; the default is the measured winner (profiles/DESIGN_history_r1-r4.md section 7.6)
             static const int chunkEnv = getenv("DMX_K3_CHUNK") ? atoi(getenv("DMX_K3_CHUNK")) : 0;
             const int cw = chunkEnv == 96 || chunkEnv == 192 ? chunkEnv : 96;
             GemmArgs c = a; // ONE launch: grid row y = chunk y (the kernel offsets its column-indexed operands by y * N)

@@ -5,7 +5,7 @@
 // the simplest addressing (one contiguous run of K floats per row). For them the 128x128 tile of igemm.hip (four
 // waves of 64x64) spends 16 ds_read_b128 and 8 staged float4 per lane on every 128 MFMAs. Here a workgroup is still
 // four waves - two independent workgroups per CU keep overlapping one's epilogue with the other's loop, which is why
-// the EIGHT-wave 256x128 tile lost - but a wave owns 128x64 outputs (8 x 4 fragments, 128
+// the EIGHT-wave 256x128 tile lost (profiles/DESIGN_history_r1-r4.md section 7.1) - but a wave owns 128x64 outputs (8 x 4 fragments, 128
 // accumulator registers) and a K-tile is 16 deep, so that two double-buffered LDS images (48 KB) fit twice per CU:
 // 12 fragment reads and 6 staged float4 per 128 MFMAs, one barrier per K-tile as before.
 //

@@ -631,7 +631,7 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
         {
             // 128-wide tiles of at least 64 rows: activation fragments straight into registers (igemm_split_lin_kernel);
             // same tile size and map, same bits. DMX_SPLIT_LIN=0 keeps the staged form (A/B comparison). Measured at 42
-            // segments: the 34 linear-layer launches 24.62 -> 24.44 ms - the loop is bound by the energy
+            // segments (profiles/DESIGN_history_r1-r4.md 7.6): the 34 linear-layer launches 24.62 -> 24.44 ms - the loop is bound by the energy
             // of the bytes it moves from L2, which this form does not change; a 256 x 128 tile with one workgroup per
             // CU (one wave per SIMD, 445 registers) was 15 % slower and is not kept.
             if constexpr (WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)

@@ -1002,7 +1002,7 @@ def test_single_segment_graph_replay_is_bit_identical(dmx, tmp_models, monkeypat
 @pytest.mark.parametrize("which", [4, 6, 3])
 def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp_models, monkeypatch):
     """DConv K1 with one read per input row (csrc/dgemm.hip dgemm_k1_ring_kernel: a register ring along the time axis;
-    DESIGN.md 7.3) against the generic direct kernel it replaces: DMX_K1_RING=0 (off), 1 (the product's rule) and 3 (ring
+    profiles/DESIGN_history_r1-r4.md 7.3) against the generic direct kernel it replaces: DMX_K1_RING=0 (off), 1 (the product's rule) and 3 (ring
     on the time branch as well, whatever the size) must give identical bits - full-size segments (walks of 8-56 steps,
     ragged last walk) and a short odd length (T = 9 frames: a walk shorter than the ring)."""
     if dmx.gemm_mode_name != "f32":
@@ -1028,7 +1028,7 @@ def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp
 
 
 def test_lin256_kernel_equals_the_128x128_tile_bitwise(dmx, tmp_models, monkeypatch):
-    """The transformer linears on the 256x128 / four-wave kernel (csrc/igemm_lin256.hip) against the 128x128
+    """The transformer linears on the 256x128 / four-wave kernel (csrc/igemm_lin256.hip; profiles/DESIGN_history_r1-r4.md 7.1) against the 128x128
     tile of igemm.hip they replace at large batches (DMX_LIN256=0): same k-ordered fmaf chain per element and the same
     summation order of the row statistics, so every output bit must agree. 38 segments: enough rows for all its
     variants (LINEAR, LINEAR + GELU, SCALE_RES + row statistics) to be selected; the plan dump confirms they are."""
@@ -1063,7 +1063,7 @@ def test_lin256_kernel_equals_the_128x128_tile_bitwise(dmx, tmp_models, monkeypa
 @pytest.mark.parametrize("which", [4, 3])
 def test_short_k_tile_equals_the_128x96_tile_bitwise(which, dmx, tmp_models, monkeypatch):
     """Short-K ops of the 128x96 tile family (K <= 160: the level-1 1x1 rewrites, the time branch's last k3 rewrite) run on
-    a 256x96 tile with 16-deep K-tiles at large batches (plan.cpp); DMX_SHORTK=0 keeps them on the 128x96
+    a 256x96 tile with 16-deep K-tiles at large batches (plan.cpp, profiles/DESIGN_history_r1-r4.md 7.1); DMX_SHORTK=0 keeps them on the 128x96
     tile. Same column decomposition and k order: identical bits (htdemucs-4s and hdemucs_mmi)."""
     if dmx.gemm_mode_name != "f32":
         pytest.skip("compares fp32-MFMA tile variants / a kernel both modes share: run once, in the f32 pass")

@@ -187,7 +187,7 @@ def test_tile_choice_counts_workgroups_per_xcd(interp, tmp_models):
     """The igemm tile map deals ROW tiles round-robin to the 8 XCDs (all column tiles of a row tile on one XCD), so the
     cost model counts the workgroups of the busiest XCD: decoder.0.rewrite at 4 segments is 84 x 6 tiles of 128x128 =
     11 row tiles on four of the XCDs = 66 workgroups for 64 slots; measured 617 us against 428 us with the 64x128 sibling
-    (DESIGN.md 7.1). The double-height experiment tile (cfg 17) is never chosen without DMX_TALL."""
+    (profiles/DESIGN_history_r1-r4.md 7.1). The double-height experiment tile (cfg 17) is never chosen without DMX_TALL."""
     interp.interp_plan_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     interp.interp_create_plan.restype = ctypes.c_void_p
     interp.interp_create_plan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]

@@ -1,4 +1,4 @@
-// gemm_fp16x3.hip — standalone prototype (NOT product code) of the "next lever" of DESIGN.md 7.8: the linear-layer split
+// gemm_fp16x3.hip — standalone prototype (NOT product code) of the "next lever" of profiles/DESIGN_history_r1-r4.md 7.8: the linear-layer split
 // GEMM of csrc/igemm_split.hip (igemm_split_lin_kernel: four waves stacked in M, activation fragments loaded straight into
 // registers and split there, weight planes through LDS, 128 x 128 tile, K-tile 32) with
 //   ARITH 0: bf16 terms, a = a1 + a2 + a3, w = w1 + w2, five v_mfma_f32_16x16x32_bf16 per block (the product's arithmetic)

@@ -1,4 +1,4 @@
-// split_fp16.hip — the exactness domain of a three-term fp16 split on the device (the "next lever" of DESIGN.md 7.8; not
+// split_fp16.hip — the exactness domain of a three-term fp16 split on the device (the "next lever" of profiles/DESIGN_history_r1-r4.md 7.8; not
 // product code). x = h1 + h2 + h3, h1 = fp16(x), h2 = fp16(x - h1), h3 = fp16(x - h1 - h2), conversions round-to-nearest-even.
 // Prediction: exact for 0.5 <= |x| <= 65504 (11 + 11 + 2 significand bits, the last one at 2^-24 = fp16's smallest
 // subnormal); below 0.5 the error is at most 2^-25; above 65504 h1 is inf. Prints, per binade of |x|, how many of the
