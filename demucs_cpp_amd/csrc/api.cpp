@@ -138,9 +138,10 @@ extern "C" int dmx_debug_split_activations(int device, const float *x, int64_t n
 
 // an op may use the split kernel when a kernel exists for its (tile, prologue, epilogue) and every weight it reads is the
 // exact sum of its two bf16 planes (true for tensors that come straight from the fp16 file; derived ones keep fp32)
-static bool split_ok(const dmx_ctx *c, const IGemm &g)
+static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g);
+static bool split_ok(const dmx_ctx *c, const IGemm &g) { return split_ok_model(c, c->m, g); }
+static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
 {
-    const dmx_model *m = c->m;
     static const bool igemmSplitOff = getenv("DMX_IGEMM_SPLIT") && atoi(getenv("DMX_IGEMM_SPLIT")) == 0; // A/B: fp32 GEMMs in split contexts
     if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb || igemmSplitOff)
         return false;
@@ -613,7 +614,13 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
     if (m->device != c->m->device || m->pm.arch != c->m->pm.arch || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
         m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
+    bool sameDecisions = true; // (the lists differ between the models of a bag - derived tensors - without changing any decision)
     if (m->inexactW != c->m->inexactW)
+        for (const auto &kv : c->plans)
+            for (const Op &op : kv.second->ops)
+                if (op.kind == OP_IGEMM && (split_ok_model(c, m, op.g) ? 1 : 0) != op.g.split)
+                    sameDecisions = false;
+    if (!sameDecisions)
     {
         // the cached plans (and captured graphs) decided per op between the exact-split and the fp32 kernel from the OLD
         // model's list of weights that are not two-plane representable: decide again for this model
