@@ -41,6 +41,14 @@ def _check_line(d, kernel_stats_csv, rnd=3, items=42, track_s=240.0):
         assert not isinstance(v, (dict, list)), k
     assert cfg["track_4min_host_xRT"] > 100 and cfg["track_4min_host_wall_s"] > 0 and cfg["track_4min_host_MB_in_out"] > 400
     assert cfg["track_strong_ranks"] == d["n_gpus"] and cfg["track_strong_xRT"] > 100 and cfg["single_segment_latency_ms"] > 0
+    if rnd >= 5:
+        # round 5: the whole path against its own roofline, counter traffic over algorithmic bytes, the sustained clock of the
+        # dominant class, and the single-segment point priced at the arithmetic that ran
+        assert 0.3 < r["whole_path_frac"] < 0.8 and 1.9 < r["effective_clock_ghz"] <= 2.45 and r["peak_clock_ghz"] == 2.4
+        assert r["traffic"] is None or (r["traffic_ratio"] is not None and abs(r["traffic_ratio"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3)
+        if cfg.get("single_segment_roofline_frac") is not None:
+            assert cfg["single_segment_peak_tflops"] == 503.3
+            assert abs(cfg["single_segment_roofline_frac"] - cfg["single_segment_tflops"] / 503.3) < 2e-3
     if rnd == 3:
         assert cfg["gemm_path"].startswith("f32 MFMA")  # round 3: the operand split was an opt-in experiment
         assert cfg["experiment_bf16x3_split_xRT"] is None or cfg["experiment_bf16x3_split_xRT"] > d["value"]
@@ -97,6 +105,26 @@ def test_committed_round4_bench_lines():
     sweep = [json.loads(x) for x in open(os.path.join(ROOT, "profiles", "r04_bench_4s_b1_b4_b12_b24.jsonl")) if x.strip()]
     ms = [x["config"]["ms_per_segment"] for x in sweep]
     assert len(ms) == 4 and ms == sorted(ms, reverse=True) and ms[-1] > d["config"]["ms_per_segment"]
+
+
+def test_committed_round5_bench_lines():
+    rd = lambda n: json.loads(open(os.path.join(ROOT, "profiles", n)).read())
+    d = rd("r05_bench_4s_b42.json")
+    assert "htdemucs-4s" in d["metric"] and "configs[2]" in d["metric"]
+    _check_line(d, "r05_kernel_stats_b42_by_class.csv", rnd=5)
+    assert d["value"] >= 2700 and d["config"]["ms_per_segment"] <= 2.1 and d["roofline"]["traffic"] is not None
+    for name, key in (("r05_bench_6s_b42.json", "configs[3]"), ("r05_bench_ft_b42.json", "configs[4]")):
+        x = rd(name)
+        assert key in x["metric"] and x["config"]["gemm_path"].startswith("bf16x3") and x["config"]["outputs_finite"] is True
+        assert 0.3 < x["roofline"]["whole_path_frac"] < 0.8
+    assert rd("r05_bench_ft_b42.json")["config"]["segments_per_gpu_per_step"] == 168
+    assert "hdemucs_mmi" in rd("r05_bench_v3_b42.json")["metric"]
+    sweep = [json.loads(x) for x in open(os.path.join(ROOT, "profiles", "r05_bench_4s_b1_b4_b12_b24.jsonl")) if x.strip()]
+    ms = [x["config"]["ms_per_segment"] for x in sweep]
+    assert len(ms) == 4 and ms == sorted(ms, reverse=True) and ms[-1] > d["config"]["ms_per_segment"]
+    # the committed traffic file of this round is the one bench.py will quote from now on
+    t = rd("r05_traffic_bf16x3.json")
+    assert t["batch"] == 42 and t["gemm"] == "bf16x3" and "igemm_split_128x128" in t["classes"]
 
 
 def test_round2_bench_line_still_parses():
