@@ -83,7 +83,7 @@ extern "C"
      *                   (a = a1 + a2 + a3, round-to-nearest splits: exact for 2^-109 <= |a| <= 3.3895e38, within 2^-125 below,
      *                   non-finite above), a weight - an fp16
      *                   number in the file - of two (w = w1 + w2: exact), and a w is accumulated in fp32 from five exact
-     *                   partial products; the dropped a3 w2 is <= 2^-24 |a w| (DESIGN.md section 7). MI355X's bf16 MFMA
+     *                   partial products; the dropped a3 w2 is <= 2^-24 |a w| (DESIGN.md section 2.5). MI355X's bf16 MFMA
      *                   rate is 16x its fp32 MFMA rate. Ops whose weights are not fp16-exact stay on the fp32 kernels.
      * dmx_ctx_create uses the process default: DMX_GEMM_BF16X3 unless the environment says DMX_GEMM=f32 (read once), or
      * what dmx_set_default_gemm set. A

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""DESIGN.md 'FFT frames next to bf16 MFMA waves': two contexts of one model driven from two host threads on ONE GPU.
-Every run's STFT output (tap x_cac - independent of every later op) and final stems are compared bit for bit with a
-quiet single-context run. Parameters (environment): MODE=bf16x3|f32, RUNS (per thread), MB (segments per call),
-DMX_LIB (a `make variant1` build), DMX_PLAN_LANE=0 (the library's containment off: the failure shows), TAG (label)."""
+"""DESIGN.md 7.1 (the packed-fp32 erratum): two contexts of one model driven from two host threads on ONE GPU, nothing
+ordering them. Every run's STFT output (tap x_cac - independent of every later op) and final stems are compared bit for bit
+with a quiet single-context run. Parameters (environment): MODE=bf16x3|f32, RUNS (per thread), MB (segments per call),
+DMX_LIB (a `make variant1` build, e.g. the FFT kernels WITH packed fp32 arithmetic:
+`make variant1 NAME=fftpk FILE=fft FLAGS="-Xclang -target-feature -Xclang +packed-fp32-ops"` shows the failure), TAG (label).
+(The round-5 logs under profiles/ were taken while the library still had its round-4 'plan lane', switched off for the run.)"""
 import os, sys, threading
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,5 +41,5 @@ if __name__ == "__main__":
     runs = int(os.environ.get("RUNS", "16"))
     bad = run(mode, runs, int(os.environ.get("MB", "2")))
     lib = os.path.basename(os.environ.get("DMX_LIB", "libdemucs_hip.so"))
-    print(f"[{os.environ.get('TAG', '')} {lib} {mode} lane={'off' if os.environ.get('DMX_PLAN_LANE') == '0' else 'on'}] "
+    print(f"[{os.environ.get('TAG', '')} {lib} {mode}] "
           f"of {2 * runs} runs: wrong STFT output {bad[0][0] + bad[1][0]}, right STFT but wrong stems {bad[0][1] + bad[1][1]}", flush=True)
