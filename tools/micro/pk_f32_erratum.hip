@@ -34,6 +34,8 @@ struct Rec
 {
     unsigned count, iter, lane, form;
     float got[2], want[2], x[2], w[2], c[2];
+    unsigned laneHist[64]; // FORM 40: failing results by lane of the wave
+    unsigned kind[4];      // FORM 40: the wrong LOW half equals x.lo + 0 (src1 read as zero) | x.lo + c.lo (op_sel ignored) | something else; [3]: wrong HIGH half
 };
 
 __device__ __forceinline__ float sfma(float a, float b, float c)
@@ -277,6 +279,14 @@ __global__ __launch_bounds__(256) void victim_kernel(const float *seed, Rec *rec
         {
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(c));
             e = v2f{sadd(x[0], c[1]), sadd(x[1], c[0])};
+            if (__float_as_uint(r[0]) != __float_as_uint(e[0]) || __float_as_uint(r[1]) != __float_as_uint(e[1]))
+            {
+                atomicAdd(&rec->laneHist[tid & 63], 1u);
+                if (__float_as_uint(r[1]) != __float_as_uint(e[1]))
+                    atomicAdd(&rec->kind[3], 1u);
+                if (__float_as_uint(r[0]) != __float_as_uint(e[0]))
+                    atomicAdd(&rec->kind[__float_as_uint(r[0]) == __float_as_uint(sadd(x[0], 0.0f)) ? 0 : (__float_as_uint(r[0]) == __float_as_uint(sadd(x[0], c[0])) ? 1 : 2)], 1u);
+            }
         }
         else if constexpr (FORM == 8)
         {
@@ -468,6 +478,7 @@ int main(int argc, char **argv)
         printf("%-58s", fe.second.c_str());
         Rec firstRec{};
         bool haveRec = false;
+        unsigned long long laneHist[64] = {0}, kindSum[4] = {0};
         for (int kind : {0, 1, 2, 4, 5})
         {
             unsigned long long total = 0;
@@ -481,6 +492,13 @@ int main(int argc, char **argv)
                 Rec h;
                 CK(hipMemcpy(&h, dRec, sizeof h, hipMemcpyDeviceToHost));
                 total += h.count;
+                if (form == 40 && h.count)
+                {
+                    for (int l = 0; l < 64; ++l)
+                        laneHist[l] += h.laneHist[l];
+                    for (int q = 0; q < 4; ++q)
+                        kindSum[q] += h.kind[q];
+                }
                 if (h.count && !haveRec)
                     firstRec = h, haveRec = true;
             }
@@ -488,6 +506,19 @@ int main(int argc, char **argv)
             fflush(stdout);
         }
         printf("\n");
+        if (form == 40 && haveRec)
+        {
+            printf("      failing results by 16-lane group of the wave:");
+            for (int g = 0; g < 4; ++g)
+            {
+                unsigned long long t = 0;
+                for (int l = 16 * g; l < 16 * g + 16; ++l)
+                    t += laneHist[l];
+                printf(" lanes %d-%d: %llu", 16 * g, 16 * g + 15, t);
+            }
+            printf("\n      wrong low half = x.lo + 0 (src1.hi read as zero): %llu, = x.lo + c.lo (op_sel ignored): %llu, other: %llu; wrong high half: %llu\n", kindSum[0],
+                   kindSum[1], kindSum[2], kindSum[3]);
+        }
         if (haveRec)
             printf("      first: iteration %u, global lane %u (lane %u of its wave): got (%.9g, %.9g) want (%.9g, %.9g); x (%.9g, %.9g) w (%.9g, %.9g) c (%.9g, %.9g)\n",
                    firstRec.iter, firstRec.lane, firstRec.lane & 63, firstRec.got[0], firstRec.got[1], firstRec.want[0], firstRec.want[1], firstRec.x[0],
