@@ -256,11 +256,19 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs pa, const Fas
                 }
                 if (PRO != PRO_NONE && !((st.ok4 >> (s * NV4 + j)) & 1u))
                     v = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef DMX_ABL_DG_NOMFMA // ablation (results wrong): the loads stay, one MFMA per fragment instead of NV4 x 4: what the memory side alone costs
+                asm volatile("" ::"v"(v));
+                if (j == 0)
+#pragma unroll
+                    for (int fj = 0; fj < NF; ++fj)
+                        acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], 0), v[0], acc[fj], 0, 0, 0);
+#else
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int fj = 0; fj < NF; ++fj)
                         acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], c), v[c], acc[fj], 0, 0, 0);
+#endif
             }
 #pragma unroll
             for (int c = 0; c < RPL; ++c)
