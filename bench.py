@@ -33,10 +33,11 @@ steps.
       cli-apps/demucs_ft.cpp:221-231: 4033, 12436, 5427, 6865), stem i of the result from model i (:238-241): 4 x 42 =
       168 (model, segment) items per GPU per step, `value` = seconds of track per second for the WHOLE bag
   v3  Demucs v3 hdemucs_mmi
---gemm f32|bf16x3 selects the GEMM arithmetic of the measured context (include/demucs_hip.h DMX_GEMM_*; default: the
-library default = bf16x3, the exact operand-split path, unless the environment says DMX_GEMM=f32); at N = 1 the OTHER
-mode is measured on the same workload in the same process and reported as config.f32_mfma_xRT / _ms_per_segment (or
-config.bf16x3_xRT / ... when the run itself is the fp32 MFMA path).
+--gemm f32|bf16x3|fp16x3 selects the GEMM arithmetic of the measured context (include/demucs_hip.h DMX_GEMM_*; default: the
+library default = bf16x3, the exact operand-split path, unless the environment says otherwise through DMX_GEMM); at N = 1
+the OTHER modes are measured on the same workload in the same process and reported as config.f32_mfma_xRT /
+_ms_per_segment (config.bf16x3_xRT / ... when the run itself is the fp32 MFMA path) and config.fp16x3_xRT / ... - the
+opt-in mode whose linear layers use fp16 terms under a per-row scale (bounded, not exact: never `value` unless asked for).
 
 config also reports, as SCALAR keys, measured in this same run:
   track_4min_host_xRT / track_4min_host_wall_s   (N = 1) the same track end to end with HOST buffers in and out
@@ -82,6 +83,8 @@ FT_NAMES = ("drums", "bass", "other", "vocals")
 def kernel_peak(kernel_class):
     """fp32-equivalent MFMA peak of a kernel class: the exact-split kernels issue 5 (GEMM: a1w1, a1w2, a2w1, a2w2, a3w1)
     or 6 (attention: both operands are activations) bf16 MFMAs per fp32 product term."""
+    if kernel_class.startswith("igemm_splith"):
+        return PEAK_TFLOPS_BF16_MFMA / 3  # fp16 terms (DMX_GEMM_FP16X3): three MFMAs per product term, same pipe rate as bf16
     if kernel_class.startswith("igemm_split"):
         return PEAK_TFLOPS_BF16_MFMA / 5
     if kernel_class.startswith("attention_split"):
@@ -141,7 +144,7 @@ def main():
                     help="segments per GPU (and per model of the bag) per step; 42 = the segments of configs[2]'s 4-minute track")
     ap.add_argument("--model", default="4s", choices=["4s", "6s", "ft", "v3"],
                     help="4s: htdemucs (the BASELINE metric); 6s: the 6-source model of configs[3]; ft: the fine-tuned bag of configs[4]; v3: hdemucs_mmi")
-    ap.add_argument("--gemm", default=None, choices=["f32", "bf16x3"], help="GEMM arithmetic of the measured context (default: library default)")
+    ap.add_argument("--gemm", default=None, choices=["f32", "bf16x3", "fp16x3"], help="GEMM arithmetic of the measured context (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
@@ -207,10 +210,12 @@ def main():
     models = [dmx.Model(p, local_rank) for p in mpaths]
     M = len(models)
     S = models[0].n_sources
-    gemm_names = {"f32": dmx.GEMM_F32, "bf16x3": dmx.GEMM_BF16X3}
+    gemm_names = {"f32": dmx.GEMM_F32, "bf16x3": dmx.GEMM_BF16X3, "fp16x3": dmx.GEMM_FP16X3}
     primary = args.gemm or dmx.GEMM_NAMES[dmx.default_gemm()]
-    other = "bf16x3" if primary == "f32" else "f32"
-    other_key = "bf16x3" if other == "bf16x3" else "f32_mfma"
+    # the other arithmetics, measured after the timed region on the same buffers (config.<key>_xRT): the fp32 MFMA path (or
+    # bf16x3 when the run itself is fp32) and the opt-in fp16-term mode, which is never `value` unless --gemm fp16x3 asks
+    others = [g for g in ("f32", "bf16x3", "fp16x3") if g != primary and not (primary == "fp16x3" and g == "bf16x3")]
+    other_keys = {"f32": "f32_mfma", "bf16x3": "bf16x3", "fp16x3": "fp16x3"}
     ctx = dmx.Context(models[0], SEG, B, gemm=gemm_names[primary])
 
     # Everything device-side is ordered on ONE torch stream: the library enqueues on it
@@ -376,17 +381,18 @@ def main():
         finite = finite and bool(torch.isfinite(track_out).all().item())
 
     # ---- the other GEMM mode on the same workload, same process, same buffers (N = 1)
-    other_run = None
+    other_runs = {}
     if world == 1 and not (args.no_other_gemm or args.no_split_probe) and not test_mode:
-        ctx2 = dmx.Context(models[0], SEG, B, gemm=gemm_names[other])
-        ctx2.set_stream(stream.cuda_stream)
-        state["ctx"] = ctx2
-        dt2 = timed_run()
-        other_run = {"xRT": round(n_track / 44100.0 * args.steps / dt2, 2), "ms_per_segment": round(dt2 / args.steps / (B * M) * 1e3, 3),
-                     "finite": bool(torch.isfinite(track_out).all().item())}
-        state["ctx"] = ctx
-        torch.cuda.synchronize()
-        ctx2.close()
+        for other in others:
+            ctx2 = dmx.Context(models[0], SEG, B, gemm=gemm_names[other])
+            ctx2.set_stream(stream.cuda_stream)
+            state["ctx"] = ctx2
+            dt2 = timed_run()
+            other_runs[other] = {"xRT": round(n_track / 44100.0 * args.steps / dt2, 2), "ms_per_segment": round(dt2 / args.steps / (B * M) * 1e3, 3),
+                                 "finite": bool(torch.isfinite(track_out).all().item())}
+            state["ctx"] = ctx
+            torch.cuda.synchronize()
+            ctx2.close()
     if M > 1:
         ctx.set_model(models[0])
 
@@ -538,7 +544,8 @@ def main():
         wl = {"4s": "htdemucs-4s", "6s": "htdemucs-6s (configs[3] model)", "v3": "hdemucs_mmi (v3)",
               "ft": "htdemucs_ft bag of 4 fine-tuned 4-source models (configs[4]), every model over every segment, stem i from model i"}[args.model]
         arith = {"f32": "fp32 MFMA compute (v_mfma_f32_16x16x4_f32)",
-                 "bf16x3": "fp32 products from exact bf16 operand splits (a = a1+a2+a3, w = w1+w2) on the bf16 MFMA pipe, fp32 accumulate"}
+                 "bf16x3": "fp32 products from exact bf16 operand splits (a = a1+a2+a3, w = w1+w2) on the bf16 MFMA pipe, fp32 accumulate",
+                 "fp16x3": "OPT-IN mode: as bf16x3, the transformer's linear layers with three fp16 activation terms under a per-row power-of-two scale x one fp16 weight (bounded, not exact)"}
         metric = {"4s": "audio-sec/s (xRT) htdemucs-4s 44.1kHz stereo, ~4-min track with overlap-add (BASELINE configs[2])",
                   "6s": "audio-sec/s (xRT) htdemucs-6s 44.1kHz stereo, ~4-min track with overlap-add (BASELINE configs[3] workload)",
                   "ft": "audio-sec/s (xRT) htdemucs_ft bag-of-4, 44.1kHz stereo, ~4-min track with overlap-add (BASELINE configs[4] workload)",
@@ -554,7 +561,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if primary == "f32" else "f32 (exact bf16x3 operand split, fp32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (exact bf16x3 operand split, fp32 accumulate)",
+                      "fp16x3": "f32 (bf16x3 operand split; linear layers fp16x3 under a per-row scale, fp32 accumulate)"}[primary],
             "data": "synthetic",
             "config": {"workload": wl + " f16-weights, " + arith[primary] + ": "
                                    + (f"one 4-minute track literally (10 584 000 samples, shift {shifts if M > 1 else shifts[0]}, {B} segments of 343980"
@@ -576,9 +584,8 @@ def main():
                        "ms_per_segment": round(elapsed / args.steps / (B * M) * 1e3, 3), "outputs_finite": finite,
                        "gemm_path": primary + ": " + arith[primary],
                        # the other GEMM arithmetic on the same workload, measured in this process right after the timed region
-                       f"{other_key}_xRT": None if other_run is None else other_run["xRT"],
-                       f"{other_key}_ms_per_segment": None if other_run is None else other_run["ms_per_segment"],
-                       f"{other_key}_outputs_finite": None if other_run is None else other_run["finite"],
+                       **{f"{other_keys[g]}_{k2}": (None if g not in other_runs else other_runs[g][k1])
+                          for g in others for k1, k2 in (("xRT", "xRT"), ("ms_per_segment", "ms_per_segment"), ("finite", "outputs_finite"))},
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        "parallelism": f"segment-sharded x{world}"},

@@ -31,13 +31,13 @@ EXPORTS = [
     "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
-    "dmx_ctx_create_gemm", "dmx_ctx_gemm", "dmx_default_gemm", "dmx_set_default_gemm", "dmx_debug_split_weights", "dmx_debug_split_activations",
+    "dmx_ctx_create_gemm", "dmx_ctx_gemm", "dmx_default_gemm", "dmx_set_default_gemm", "dmx_debug_split_weights", "dmx_debug_split_activations", "dmx_debug_split_activations_fp16",
     "dmx_model_arch", "dmx_engine_arch", "dmx_engine_transport", "dmx_engine_set_finish", "dmx_engine_finish", "dmx_engine_root_ctx", "dmx_engine_track_infer", "dmx_engine_partition",
 ]
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_P2P = 0, 1, 2
-GEMM_F32, GEMM_BF16X3 = 0, 1
-GEMM_NAMES = {GEMM_F32: "f32", GEMM_BF16X3: "bf16x3"}
+GEMM_F32, GEMM_BF16X3, GEMM_FP16X3 = 0, 1, 2  # include/demucs_hip.h DMX_GEMM_* (FP16X3: opt-in, linear layers with fp16 terms)
+GEMM_NAMES = {GEMM_F32: "f32", GEMM_BF16X3: "bf16x3", GEMM_FP16X3: "fp16x3"}
 FINISH_ROOT, FINISH_OWNER = 0, 1
 
 _lib = None
@@ -78,6 +78,7 @@ def lib():
         L.dmx_debug_split_weights.argtypes = [fp, i64, fp, fp]
         L.dmx_debug_split_weights.restype = i64
         L.dmx_debug_split_activations.argtypes = [ci, fp, i64, fp]
+        L.dmx_debug_split_activations_fp16.argtypes = [ci, fp, i64, ci, fp]
         L.dmx_ctx_free.argtypes = [vp]
         L.dmx_ctx_segment_samples.argtypes = [vp]
         L.dmx_ctx_segment_samples.restype = i64
@@ -147,7 +148,7 @@ def default_gemm() -> int:
 
 
 def set_default_gemm(gemm: int):
-    """GEMM arithmetic of contexts (and engines) created from now on: GEMM_F32 | GEMM_BF16X3."""
+    """GEMM arithmetic of contexts (and engines) created from now on: GEMM_F32 | GEMM_BF16X3 | GEMM_FP16X3."""
     _chk(lib().dmx_set_default_gemm(gemm))
 
 
@@ -165,6 +166,14 @@ def split_activations(x: np.ndarray, device: int = 0) -> np.ndarray:
     x = np.ascontiguousarray(x, np.float32).ravel()
     planes = np.zeros((3, x.size), np.uint16)
     _chk(lib().dmx_debug_split_activations(device, x.ctypes.data, x.size, planes.ctypes.data))
+    return planes
+
+
+def split_activations_fp16(x: np.ndarray, scale_exp: int = 0, device: int = 0) -> np.ndarray:
+    """(3, n) fp16 bit patterns h1, h2, h3 of the fp16-term split of x * 2^scale_exp (GEMM_FP16X3; runs on the GPU)."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    planes = np.zeros((3, x.size), np.uint16)
+    _chk(lib().dmx_debug_split_activations_fp16(device, x.ctypes.data, x.size, int(scale_exp), planes.ctypes.data))
     return planes
 
 

@@ -87,16 +87,16 @@ extern "C" int dmx_default_gemm(void)
         // default since round 4: the exact operand-split path (every -m gpu parity test runs in both modes; DESIGN.md
         // section 2.5); DMX_GEMM=f32 selects the fp32 MFMA kernels
         const char *e = getenv("DMX_GEMM");
-        g = e && !strcmp(e, "f32") ? DMX_GEMM_F32 : DMX_GEMM_BF16X3;
-        if (e && *e && strcmp(e, "f32") && strcmp(e, "bf16x3")) // a typo must not silently select the other arithmetic
-            fprintf(stderr, "demucs_hip: DMX_GEMM=%s is not one of {f32, bf16x3}; using bf16x3 (the default)\n", e);
+        g = e && !strcmp(e, "f32") ? DMX_GEMM_F32 : e && !strcmp(e, "fp16x3") ? DMX_GEMM_FP16X3 : DMX_GEMM_BF16X3;
+        if (e && *e && strcmp(e, "f32") && strcmp(e, "bf16x3") && strcmp(e, "fp16x3")) // a typo must not silently select the other arithmetic
+            fprintf(stderr, "demucs_hip: DMX_GEMM=%s is not one of {f32, bf16x3, fp16x3}; using bf16x3 (the default)\n", e);
         g_defaultGemm.store(g);
     }
     return g;
 }
 extern "C" int dmx_set_default_gemm(int gemm)
 {
-    if (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3)
+    if (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3 && gemm != DMX_GEMM_FP16X3)
         return fail(DMX_ERR_ARG, "dmx_set_default_gemm: unknown mode %d", gemm);
     g_defaultGemm.store(gemm);
     return DMX_OK;
@@ -136,6 +136,49 @@ extern "C" int dmx_debug_split_activations(int device, const float *x, int64_t n
     return DMX_OK;
 }
 
+extern "C" int dmx_debug_split_activations_fp16(int device, const float *x, int64_t n, int scale_exp, unsigned short *planes)
+{
+    if (!x || !planes || n < 1 || scale_exp < -126 || scale_exp > 126)
+        return fail(DMX_ERR_ARG, "dmx_debug_split_activations_fp16: invalid argument");
+    if (device < 0 || device >= dmx_device_count())
+        return fail(DMX_ERR_NO_DEVICE, "dmx_debug_split_activations_fp16: no such HIP device (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    float *dx = nullptr;
+    unsigned short *dp = nullptr;
+    HIPCHK(hipMalloc((void **)&dx, sizeof(float) * (size_t)n));
+    hipError_t e = hipMalloc((void **)&dp, sizeof(unsigned short) * 3 * (size_t)n);
+    if (e == hipSuccess)
+        e = hipMemcpy(dx, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        launch_split3h_debug(dx, n, scale_exp, dp, nullptr);
+        e = hipMemcpy(planes, dp, sizeof(unsigned short) * 3 * (size_t)n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dx);
+    if (dp)
+        (void)hipFree(dp);
+    if (e != hipSuccess)
+        return fail(DMX_ERR_HIP, "dmx_debug_split_activations_fp16: %s", hipGetErrorString(e));
+    return DMX_OK;
+}
+
+// the geometry of an op as the kernels see it (no pointers): what launch_op passes and what the launchers' own predicates
+// (linear-layer addressing, ...) read when they are asked whether a kernel exists
+static void fill_gemm_geometry(GemmArgs &k, const IGemm &g)
+{
+    k.xBS = g.xBatchStride;
+    k.B = g.B, k.P1 = g.P1, k.P0 = g.P0, k.L1 = g.L1, k.L0 = g.L0, k.Cin = g.Cin;
+    k.S1 = g.S1, k.stride1 = g.stride1, k.dil1 = g.dil1, k.pad1 = g.pad1;
+    k.seg0 = g.seg0, k.stride0 = g.stride0, k.pad0 = g.pad0, k.K = g.K, k.Kp = g.Kp;
+    k.pro = g.pro, k.G0 = g.G0;
+    k.N = g.N, k.Np = g.Np;
+    k.epi = g.epi, k.act = g.act, k.yBS = g.yBatchStride, k.ldy = g.ldy;
+    k.NB = g.NB, k.tableScale = g.tableScale;
+    k.Lout = g.Lout, k.Cout = g.Cout, k.trS = g.trS, k.trOff = g.trOff;
+    k.kvCol0 = g.kvCol0, k.kvT = g.kvT, k.kvH = g.kvH, k.kvHs = g.kvHs;
+    k.M = (i64)g.B * g.P1 * g.P0;
+}
+
 // an op may use the split kernel when a kernel exists for its (tile, prologue, epilogue) and every weight it reads is the
 // exact sum of its two bf16 planes (true for tensors that come straight from the fp16 file; derived ones keep fp32)
 static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g);
@@ -143,7 +186,7 @@ static bool split_ok(const dmx_ctx *c, const IGemm &g) { return split_ok_model(c
 static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
 {
     static const bool igemmSplitOff = getenv("DMX_IGEMM_SPLIT") && atoi(getenv("DMX_IGEMM_SPLIT")) == 0; // A/B: fp32 GEMMs in split contexts
-    if (c->gemm != DMX_GEMM_BF16X3 || !m->dWb || igemmSplitOff)
+    if (c->gemm == DMX_GEMM_F32 || !m->dWb || igemmSplitOff)
         return false;
     GemmArgs k{};
     k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
@@ -156,6 +199,25 @@ static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
     auto it = std::lower_bound(m->inexactW.begin(), m->inexactW.end(), lo);
     return it == m->inexactW.end() || *it >= hi;
 }
+
+// 0: the op keeps its fp32 kernel; 1: bf16 terms (split_ok); 2: fp16 terms - contexts of DMX_GEMM_FP16X3, ops for which the
+// fp16-term kernel exists (the linear-layer kernel, igemm_split.hip) and whose weights are all fp16 numbers
+static int split_kind_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
+{
+    if (!split_ok_model(c, m, g))
+        return 0;
+    if (c->gemm != DMX_GEMM_FP16X3 || !m->dWh || !g.hterms)
+        return 1;
+    GemmArgs k{};
+    fill_gemm_geometry(k, g);
+    k.Wb1 = k.Wb2 = m->dWh;
+    if (launch_igemm_split(g.cfg, k, nullptr, true, 1) != 0)
+        return 1;
+    const i64 lo = g.w_w, hi = g.w_w + (i64)g.Np * g.Kp;
+    auto it = std::lower_bound(m->inexactH.begin(), m->inexactH.end(), lo);
+    return (it == m->inexactH.end() || *it >= hi) ? 2 : 1;
+}
+static int split_kind(const dmx_ctx *c, const IGemm &g) { return split_kind_model(c, c->m, g); }
 
 int dmx_model_upload(dmx_model *m, const float *blob)
 {
@@ -183,6 +245,21 @@ int dmx_model_upload(dmx_model *m, const float *blob)
                 m->inexactW.push_back((i64)i);
         HIPCHK(hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short)));
         HIPCHK(hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
+    {
+        // DMX_GEMM_FP16X3: every blob element as ONE fp16 number (round to nearest). Exact for everything that comes straight
+        // from the fp16 weight file; the rest is listed, and an op that touches a listed element keeps bf16 terms (split_kind).
+        std::vector<unsigned short> plane(m->blobFloats + 1024, 0);
+        m->inexactH.clear();
+        for (size_t i = 0; i < m->blobFloats; ++i)
+        {
+            const _Float16 h = (_Float16)blob[i];
+            memcpy(&plane[i], &h, 2);
+            if (!((float)h == blob[i]))
+                m->inexactH.push_back((i64)i);
+        }
+        HIPCHK(hipMalloc((void **)&m->dWh, plane.size() * sizeof(unsigned short)));
+        HIPCHK(hipMemcpy(m->dWh, plane.data(), plane.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     return DMX_OK;
 }
@@ -218,6 +295,8 @@ extern "C" void dmx_model_free(dmx_model *m)
         (void)hipFree(m->dW);
         if (m->dWb)
             (void)hipFree(m->dWb);
+        if (m->dWh)
+            (void)hipFree(m->dWh);
     }
     delete m;
 }
@@ -264,7 +343,7 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     // plan is rebuilt in the fp32-K/V form.
     const bool planesOff = getenv("DMX_KV_PLANES") && atoi(getenv("DMX_KV_PLANES")) == 0; // (read per plan: tests switch it)
     static const bool attSplitOffEnv = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0;
-    opts.kvPlanes = c->gemm == DMX_GEMM_BF16X3 && !planesOff && !attSplitOffEnv && c->m->pm.arch != 3 ? 1 : 0;
+    opts.kvPlanes = c->gemm != DMX_GEMM_F32 && !planesOff && !attSplitOffEnv && c->m->pm.arch != 3 ? 1 : 0;
     build_plan(c->m->pm, c->seg, batch, *p, opts);
     if (opts.kvPlanes)
     {
@@ -285,13 +364,13 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     for (Op &op : p->ops)
     {
         if (op.kind == OP_IGEMM)
-            op.g.split = split_ok(c, op.g) ? 1 : 0;
+            op.g.split = split_kind(c, op.g);
         if (op.kind == OP_ATTENTION)
         {
             AttnArgs t{};
             t.hs = op.at.hs;
             static const bool attSplitOff = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0; // A/B: fp32 attention in split contexts
-            op.at.split = c->gemm == DMX_GEMM_BF16X3 && !attSplitOff && launch_attention_split(t, nullptr, true) == 0 ? 1 : 0;
+            op.at.split = c->gemm != DMX_GEMM_F32 && !attSplitOff && launch_attention_split(t, nullptr, true) == 0 ? 1 : 0;
         }
     }
     Plan *raw = p.get();
@@ -530,6 +609,17 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     }
     HIPCHK(hipMalloc((void **)&c->dPartials, sizeof(double) * 2 * dmx_ctx::kStatBlocks));
     HIPCHK(hipMalloc((void **)&c->dStats, sizeof(float) * 4));
+    if (gemm == DMX_GEMM_FP16X3)
+    {
+        // per-row scales of the linear layer in flight (launch_rowscale): two floats per A row, one buffer per stream of the plan
+        i64 maxM = 0;
+        for (const Op &op : p->ops)
+            if (op.kind == OP_IGEMM && op.g.split == 2)
+                maxM = std::max(maxM, (i64)op.g.B * op.g.P1 * op.g.P0);
+        if (maxM > 0)
+            for (int k = 0; k < 2; ++k)
+                HIPCHK(hipMalloc((void **)&c->dRowScale[k], sizeof(float) * 2 * (size_t)maxM));
+    }
     HIPCHK(hipMalloc((void **)&c->dStatus, sizeof(unsigned)));
     HIPCHK(hipMemset(c->dStatus, 0, sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&c->hStatus, sizeof(unsigned), hipHostMallocDefault));
@@ -546,7 +636,7 @@ extern "C" int dmx_ctx_gemm(const dmx_ctx *c) { return c ? c->gemm : -1; }
 
 extern "C" int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, int max_batch, int gemm, dmx_ctx **out)
 {
-    if (!m || !out || max_batch < 1 || max_batch > 64 || (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3))
+    if (!m || !out || max_batch < 1 || max_batch > 64 || (gemm != DMX_GEMM_F32 && gemm != DMX_GEMM_BF16X3 && gemm != DMX_GEMM_FP16X3))
         return fail(DMX_ERR_ARG, "dmx_ctx_create: invalid argument");
     *out = nullptr;
     if (segment_samples == 0)
@@ -593,7 +683,7 @@ dmx_ctx::~dmx_ctx()
         (void)hipEventDestroy(evFork);
     if (evJoin)
         (void)hipEventDestroy(evJoin);
-    for (void *p : {(void *)dA, (void *)dPartials, (void *)dStats, (void *)dStatus, (void *)bAudio.p, (void *)bTmp.p, (void *)bMix.p,
+    for (void *p : {(void *)dA, (void *)dPartials, (void *)dStats, (void *)dStatus, (void *)dRowScale[0], (void *)dRowScale[1], (void *)bAudio.p, (void *)bTmp.p, (void *)bMix.p,
                     (void *)bSegOut.p, (void *)bOut.p})
         if (p)
             (void)hipFree(p);
@@ -615,10 +705,10 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
         m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
     bool sameDecisions = true; // (the lists differ between the models of a bag - derived tensors - without changing any decision)
-    if (m->inexactW != c->m->inexactW)
+    if (m->inexactW != c->m->inexactW || m->inexactH != c->m->inexactH)
         for (const auto &kv : c->plans)
             for (const Op &op : kv.second->ops)
-                if (op.kind == OP_IGEMM && (split_ok_model(c, m, op.g) ? 1 : 0) != op.g.split)
+                if (op.kind == OP_IGEMM && split_kind_model(c, m, op.g) != op.g.split)
                     sameDecisions = false;
     if (!sameDecisions)
     {
@@ -735,6 +825,19 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         k.zero = A + zeroOff;
         k.dbg = g_dbg;
         k.Wb1 = k.Wb2 = nullptr;
+        k.rowScale = nullptr;
+        if (g.split == 2 && c->m->dWh && c->dRowScale[op.stream ? 1 : 0])
+        {
+            // fp16 terms (opt-in DMX_GEMM_FP16X3): the row scales of this op's A operand first, then the linear-layer kernel on
+            // one fp16 weight plane
+            float *rs = c->dRowScale[op.stream ? 1 : 0];
+            launch_rowscale(k, rs, s);
+            k.rowScale = rs;
+            k.Wb1 = k.Wb2 = c->m->dWh + g.w_w;
+            if (launch_igemm_split(g.cfg, k, s, false, 1) == 0)
+                break;
+            k.rowScale = nullptr;
+        }
         if (g.split && c->m->dWb)
         {
             k.Wb1 = c->m->dWb + g.w_w;
@@ -1313,6 +1416,8 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
                                                             nullptr, nullptr};
             if (splitNames[g.cfg])
                 kernel = splitNames[g.cfg];
+            if (g.split == 2) // fp16 terms (+ the row-scale pre-pass): its own roofline class (2516.6 / 3)
+                kernel = g.cfg == 0 ? "igemm_splith_128x128" : g.cfg == 7 ? "igemm_splith_64x128" : kernel;
         }
         flops = 2.0 * M * g.N * g.K;
         double in = (double)g.B * g.L1 * g.L0 * g.Cin, w = (double)g.N * g.K, out = 0;

@@ -40,6 +40,8 @@ struct dmx_model
                                    // plane 2 starts at element blobFloats + 512
     std::vector<dmx::i64> inexactW; // blob elements that are NOT the exact sum of their two planes (derived tensors), ascending;
                                     // filled at upload, so replicas on other devices (dmx_model_clone) agree with the original
+    unsigned short *dWh = nullptr; // one fp16 plane of the blob (GEMM_FP16X3 contexts: the linear layers' weights as ONE exact term)
+    std::vector<dmx::i64> inexactH; // blob elements that are not fp16 numbers, ascending (same role as inexactW)
     int device = 0;
 };
 // uploads `blob` (blobFloats floats) as the weights of `m` on m->device
@@ -80,6 +82,7 @@ struct dmx_ctx
     static const int kStatBlocks = 256;
     DevBuf bAudio, bTmp, bMix, bSegOut, bOut;
     float *dStats = nullptr;            // 4 floats
+    float *dRowScale[2] = {nullptr, nullptr}; // GEMM_FP16X3: per-row scales of the linear layer in flight, one buffer per stream of the plan
     unsigned *dStatus = nullptr;        // device status word: raised by a kernel whose bounded spin timed out (v3.hip LSTM)
     unsigned *hStatus = nullptr;        // pinned host copy (dmx_ctx_sync_checked)
     std::vector<hipEvent_t> batchEvents; // progress reporting without host synchronisation of the stream

@@ -70,6 +70,41 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned &h1, unsi
     h3 = bf16_pk_rn(s0, s1);
 }
 
+// ---------------------------------------------------------------------------------------------- fp16 terms (DMX_GEMM_FP16X3, opt-in)
+// x = h1 + h2 + h3 with h1 = fp16(x), h2 = fp16(x - h1), h3 = fp16(x - h1 - h2), conversions round-to-nearest-even
+// (v_cvt_pk_f16_f32; fp16 subnormals kept). 11 + 11 + 2 significand bits: EXACT for 0.5 <= |x| <= 65504; below 0.5 the last
+// bits fall under fp16's subnormal spacing 2^-24 and the sum is within 2^-25 of x; above 65504 h1 is inf (measured per binade
+// on the device: tools/micro/split_fp16.hip, tests). The kernels only ever split x = a 2^s with the power of two s chosen per
+// ROW so that the row's largest |a 2^s| lies in [2^14, 2^15): no element can overflow, an element loses bits only when it is
+// more than 2^15 times smaller than the largest of its row, and then at most 2^-25 absolute in scaled units, i.e. 2^-39 of
+// the row's maximum. The weights of the model files ARE fp16 numbers, so a weight is ONE exact term and a product term needs
+// three MFMAs (h3 w, h2 w, h1 w) instead of five. Packed like split3_pk: low 16 bits = the term of x0, high = of x1.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3h_pk(float x0, float x1, unsigned &h1, unsigned &h2, unsigned &h3)
+{
+    const f16x2_t a = __builtin_convertvector(f32x2{x0, x1}, f16x2_t);
+    const f32x2 af = __builtin_convertvector(a, f32x2);
+    const float r0 = x0 - af[0], r1 = x1 - af[1];
+    const f16x2_t b = __builtin_convertvector(f32x2{r0, r1}, f16x2_t);
+    const f32x2 bf = __builtin_convertvector(b, f32x2);
+    const float q0 = r0 - bf[0], q1 = r1 - bf[1];
+    const f16x2_t c = __builtin_convertvector(f32x2{q0, q1}, f16x2_t);
+    h1 = __builtin_bit_cast(unsigned, a), h2 = __builtin_bit_cast(unsigned, b), h3 = __builtin_bit_cast(unsigned, c);
+}
+// the row scale of the fp16-term kernels from the row's largest magnitude: {2^s, 2^-s} with s = 14 - floor(log2 max), so the
+// scaled row's largest magnitude lies in [2^14, 2^15) - whatever finite fp32 number it was, the fp16 terms cannot overflow
+// (s >= -113 for every finite maximum). s is capped at 126 (2^-s must stay a normal number): rows whose largest magnitude is
+// below 2^-112 are scaled by 2^126 and lose at most 2^-25 of the SCALED value = 2^-151 absolute, less than fp32's smallest
+// denormal step. Rows of zeros: 2^126. inf / NaN maximum: 2^-114, the products stay non-finite.
+__device__ __forceinline__ float2 rowscale_of(float amax)
+{
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127; // floor(log2 amax) for normal numbers; -127 for denormals and zero
+    int sexp = 14 - e;
+    sexp = sexp > 126 ? 126 : sexp; // (>= -114 by construction)
+    return make_float2(__uint_as_float((unsigned)(127 + sexp) << 23), __uint_as_float((unsigned)(127 - sexp) << 23));
+}
+
 // ---------------------------------------------------------------------------------------------- tiles and rows
 // workgroup -> tile. Workgroup b is dispatched to XCD b % 8 (observed; used for speed only). With the
 // XCD-aware map all column tiles of a row tile run on the same XCD right after one another, so the

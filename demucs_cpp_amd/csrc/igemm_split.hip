@@ -34,8 +34,10 @@
 
 #if DMX_SPLIT_ABL & 128
 #define DMX_SPLIT_MFMA(a, b, c, x, y, z) (c)
+#define DMX_SPLIT_MFMA_H(a, b, c, x, y, z) (c)
 #else
 #define DMX_SPLIT_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define DMX_SPLIT_MFMA_H(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
 #endif
 
 namespace dmx
@@ -336,14 +338,21 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 // same bits (the batch / shard invariance tests run small batches on the 2 x 2 kernels and large ones on this one).
 // (Two experiments on this kernel were measured in round 5 and removed again - three staging register sets, persistent
 // workgroups with cross-tile prefetch: profiles/r05_experiments_split_gemm.md.)
-template <int WMF, int WNF, int EPI>
+// ARITH 0: bf16 terms (a = a1 + a2 + a3, w = w1 + w2: five MFMAs per block, two weight planes), the arithmetic of every other
+// split kernel. ARITH 1 (contexts of DMX_GEMM_FP16X3, opt-in): fp16 terms - the weights ARE fp16 numbers, so a weight is one
+// exact term (p.Wb1 = the fp16 plane of the blob); an activation row is first multiplied by its power-of-two scale
+// p.rowScale[m] (launch_rowscale: the row's largest magnitude lands in [2^14, 2^15), so nothing can overflow) and split into
+// three fp16 terms (igemm_common.h split3h_pk); three v_mfma_f32_16x16x32_f16 per block, one weight plane through LDS, and the
+// accumulators are multiplied by 2^-s of their row before the epilogue. Bounded, not exact (the contract: igemm_common.h).
+template <int WMF, int WNF, int EPI, int ARITH = 0>
 __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs p)
 {
     constexpr int KT = 32;
     constexpr int BM = 4 * WMF * 16, BN = WNF * 16;
-    constexpr int BR = BN / 32; // 16-byte chunks of the two weight planes per thread and K-tile
+    constexpr int NBP = ARITH ? 1 : 2;  // weight planes
+    constexpr int BR = NBP * BN / 64;   // 16-byte chunks of the weight planes per thread and K-tile
     static_assert(BN % 64 == 0, "two rows of one plane per 8-lane store group");
-    __shared__ u32x4 Bp0[2][BN][4], Bp1[2][BN][4]; // [plane][column][octet slot]
+    __shared__ u32x4 Bp0[NBP][BN][4], Bp1[NBP][BN][4]; // [plane][column][octet slot]
     float2(*rsum)[2] = reinterpret_cast<float2(*)[2]>(&Bp0[0][0][0]); // after the K loop: two runs of four fragments per row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -364,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     // activation rows of this lane: block i = rows wave * WMF * 16 + 16 i + l15, k-octet kq (rows beyond M read the last
     // valid row; their accumulators are never stored)
     unsigned aOff[WMF], bOff[BR];
+    float aScale[WMF], aInv[WMF]; // (ARITH 1) 2^s / 2^-s of this lane's row of block i
     {
         const i64 rowLen = (i64)p.L0 * p.Cin;
 #pragma unroll
@@ -372,24 +382,30 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             const i64 m = min(m0 + wave * (WMF * 16) + i * 16 + l15, p.M - 1);
             const int4 ri = row_info(p, m);
             aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
+            aScale[i] = aInv[i] = 1.0f;
+            if constexpr (ARITH == 1)
+            {
+                const float2 sc = *reinterpret_cast<const float2 *>(p.rowScale + 2 * m);
+                aScale[i] = sc.x, aInv[i] = sc.y;
+            }
         }
     }
-    // weight chunks: chunk i = plane i & 1 of column 64 (i >> 1) + 2 (tid >> 3) + ((tid >> 2) & 1), octet tid & 3
+    // weight chunks: chunk i = plane i % NBP of column 64 (i / NBP) + 2 (tid >> 3) + ((tid >> 2) & 1), octet tid & 3
     const int bOct = tid & 3;
-    auto bRowOf = [&](int i) { return 64 * (i >> 1) + 2 * (tid >> 3) + ((tid >> 2) & 1); };
+    auto bRowOf = [&](int i) { return 64 * (i / NBP) + 2 * (tid >> 3) + ((tid >> 2) & 1); };
     {
         const unsigned planeDelta = (unsigned)(p.Wb2 - p.Wb1);
 #pragma unroll
         for (int i = 0; i < BR; ++i)
         {
             const int n = min(n0 + bRowOf(i), p.Np - 1);
-            bOff[i] = ((unsigned)n * (unsigned)p.Kp + (unsigned)bOct * 8u + ((i & 1) ? planeDelta : 0u)) * 2u;
+            bOff[i] = ((unsigned)n * (unsigned)p.Kp + (unsigned)bOct * 8u + ((i % NBP) ? planeDelta : 0u)) * 2u;
         }
     }
 
     f32x4 aRaw[2][WMF][2];
     u32x4 bReg[2][BR];
-    bf16x8 aPl[2][WMF][3];
+    u32x4 aPl[2][WMF][3]; // three 16-bit planes of 8 k each (bf16 or fp16 terms)
     bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
@@ -421,6 +437,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             h1[2] = h2[2] = h3[2] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
             h1[3] = h2[3] = h3[3] = __builtin_amdgcn_perm(__float_as_uint(hi[3]), __float_as_uint(hi[2]), 0x07060302u);
         }
+        else if (ARITH)
+        {
+            const float sc = aScale[i]; // a power of two: exact
+            split3h_pk(lo[0] * sc, lo[1] * sc, h1[0], h2[0], h3[0]);
+            split3h_pk(lo[2] * sc, lo[3] * sc, h1[1], h2[1], h3[1]);
+            split3h_pk(hi[0] * sc, hi[1] * sc, h1[2], h2[2], h3[2]);
+            split3h_pk(hi[2] * sc, hi[3] * sc, h1[3], h2[3], h3[3]);
+        }
         else
         {
             split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
@@ -432,9 +456,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         // (the planes are computed HERE, between the MFMA groups: without this the compiler sinks the split of the odd
         // tiles into the next iteration's head, in front of its first fragment reads)
         asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));
-        aPl[DST][i][0] = __builtin_bit_cast(bf16x8, q1);
-        aPl[DST][i][1] = __builtin_bit_cast(bf16x8, q2);
-        aPl[DST][i][2] = __builtin_bit_cast(bf16x8, q3);
+        aPl[DST][i][0] = q1;
+        aPl[DST][i][1] = q2;
+        aPl[DST][i][2] = q3;
     };
     auto store_B = [&](auto setTag, int buf, int b0, int b1e) {
         constexpr int SET = decltype(setTag)::value;
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
                 continue;
             }
             const int row = bRowOf(i);
-            Bp[i & 1][row][bOct ^ swz(row)] = bReg[SET][i];
+            Bp[i % NBP][row][bOct ^ swz(row)] = bReg[SET][i];
         }
     };
 
@@ -477,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     __syncthreads();
     const int fslot = kq ^ swz(l15);
     constexpr int NH = WNF / 4; // column fragments are processed four at a time
-    bf16x8 b1[NH][4], b2[NH][4];
+    u32x4 b1[NH][4], b2[NH][4]; // weight fragments (b2: the second bf16 plane, ARITH 0 only)
     bool inLoop2 = false; // (ablation 256: fragments are read in the first iteration only)
     // PAR = kt & 1: the weight image, activation planes and staging register set of tile kt
     auto iteration = [&](auto parTag) {
@@ -491,12 +515,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             for (int j = 0; j < 4; ++j)
             {
                 const int r = (h * 4 + j) * 16 + l15;
-                b1[h][j] = __builtin_bit_cast(bf16x8, Bp[0][r][fslot]);
-                b2[h][j] = __builtin_bit_cast(bf16x8, Bp[1][r][fslot]);
+                b1[h][j] = Bp[0][r][fslot];
+                if (NBP == 2)
+                    b2[h][j] = Bp[NBP - 1][r][fslot];
             }
         };
         // one term of the product for the four column fragments of half h, all row blocks: 4 WMF independent accumulators
-        auto term = [&](int h, bf16x8(&b)[4], int plane) {
+        auto term = [&](int h, u32x4(&b)[4], int plane) {
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
 #pragma unroll
@@ -504,10 +529,14 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
                 {
                     // EPI_VT: the transposed product (activations as the matrix pipe's A operand): the accumulator holds C, a lane
                     // owns 4 consecutive TOKENS of one channel - the V^T pieces of the attention kernel (igemm_common.h)
-                    if constexpr (EPI == EPI_VT)
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(aPl[PAR][i][plane], b[j], acc[i][h * 4 + j], 0, 0, 0);
+                    if constexpr (ARITH == 1 && EPI == EPI_VT)
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA_H(__builtin_bit_cast(f16x8, aPl[PAR][i][plane]), __builtin_bit_cast(f16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
+                    else if constexpr (ARITH == 1)
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA_H(__builtin_bit_cast(f16x8, b[j]), __builtin_bit_cast(f16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
+                    else if constexpr (EPI == EPI_VT)
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(__builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), __builtin_bit_cast(bf16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
                     else
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(b[j], aPl[PAR][i][plane], acc[i][h * 4 + j], 0, 0, 0);
+                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
                 }
         };
         if (!(DMX_SPLIT_ABL & 256) || !inLoop2)
@@ -515,18 +544,20 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 #pragma unroll
         for (int h = 0; h < NH; ++h)
         {
-            // smallest terms first, as in igemm_split_kernel: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
+            // smallest terms first, as in igemm_split_kernel: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (fp16 terms: h3 w, h2 w, h1 w)
             term(h, b1[h], 2);
             if (h + 1 < NH && (!(DMX_SPLIT_ABL & 256) || !inLoop2))
                 read_half(h + 1); // the next half's fragments are in flight during this half's remaining MFMAs
-            term(h, b2[h], 1);
+            if (!ARITH)
+                term(h, b2[h], 1);
             // tile kt + 1: activations of set PAR ^ 1 -> planes, weight chunks -> the other image (spread over the halves)
 #pragma unroll
             for (int i = 0; i < WMF; ++i)
                 if ((i * NH) / WMF == h)
                     split_block(nextSet, other, i);
             store_B(nextSet, PAR ^ 1, h * BR / NH, (h + 1) * BR / NH);
-            term(h, b2[h], 0);
+            if (!ARITH)
+                term(h, b2[h], 0);
             term(h, b1[h], 1);
             term(h, b1[h], 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -562,6 +593,35 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         if (t == 123.456f)
             p.Y[0] = t;
         return;
+    }
+    if constexpr (ARITH == 1)
+    {
+        // back to the scale of the activations: acc = 2^s (a . w) -> a . w, a power-of-two factor per ROW (exact unless the product
+        // itself leaves fp32's range)
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            if constexpr (EPI == EPI_VT) // transposed accumulators: this lane holds tokens 16 i + 4 kq + {0..3} of its channel
+            {
+                float inv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    inv[r] = p.rowScale[2 * min(m0 + wave * (WMF * 16) + i * 16 + 4 * kq + r, p.M - 1) + 1];
+#pragma unroll
+                for (int j = 0; j < WNF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[i][j][r] *= inv[r];
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < WNF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[i][j][r] *= aInv[i];
+            }
+        }
     }
     igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
 #ifdef DMX_TIMING
@@ -599,9 +659,61 @@ void launch_split3_debug(const float *d_x, i64 n, unsigned short *d_planes, hipS
     hipLaunchKernelGGL(split3_debug_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_x, n, d_planes);
 }
 
-template <int WM_, int WN_, int MF, int NF, int PRO, int EPI>
-static void launch_split_one(const GemmArgs &a0, hipStream_t s)
+// per-row scales of a linear layer's A operand (GEMM_FP16X3): a 16-lane group per row, rows of K contiguous floats
+__global__ __launch_bounds__(256) void rowscale_kernel(const GemmArgs p, float *out)
 {
+    const int tid = threadIdx.x, l15 = tid & 15;
+    const i64 m = (i64)blockIdx.x * 16 + (tid >> 4);
+    if (m >= p.M)
+        return;
+    const int4 ri = row_info(p, m);
+    const float *row = p.X + (i64)ri.x * p.xBS + ((i64)ri.y * p.L0 + (i64)ri.z * p.stride0) * p.Cin;
+    float mx = 0.f;
+    for (int k = l15 * 4; k < p.K; k += 64)
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        // (fmaxf ignores NaN operands: a NaN element still poisons its products through the split; an inf row maximum gives 2^-100)
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (l15 == 0)
+        *reinterpret_cast<float2 *>(out + 2 * m) = rowscale_of(mx);
+}
+void launch_rowscale(const GemmArgs &a0, float *out, hipStream_t s)
+{
+    GemmArgs a = a0;
+    a.dP0 = make_fastdiv((unsigned)a.P0), a.dP1 = make_fastdiv((unsigned)a.P1);
+    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((a.M + 15) / 16)), dim3(256), 0, s, a, out);
+}
+// the kernels' fp16 split on an array under one scale 2^sexp (dmx_debug_split_activations_fp16: unit test of the split itself)
+__global__ void split3h_debug_kernel(const float *x, i64 n, float scale, unsigned short *planes)
+{
+    const i64 i = ((i64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n)
+        return;
+    const float x0 = x[i] * scale, x1 = (i + 1 < n ? x[i + 1] : 0.f) * scale;
+    unsigned h1, h2, h3;
+    split3h_pk(x0, x1, h1, h2, h3);
+    planes[i] = (unsigned short)h1, planes[n + i] = (unsigned short)h2, planes[2 * n + i] = (unsigned short)h3;
+    if (i + 1 < n)
+        planes[i + 1] = (unsigned short)(h1 >> 16), planes[n + i + 1] = (unsigned short)(h2 >> 16), planes[2 * n + i + 1] = (unsigned short)(h3 >> 16);
+}
+void launch_split3h_debug(const float *d_x, i64 n, int sexp, unsigned short *d_planes, hipStream_t s)
+{
+    const i64 pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(split3h_debug_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_x, n, ldexpf(1.0f, sexp), d_planes);
+}
+
+// arith 0: bf16 terms (every tile of the table below); arith 1: fp16 terms - only where igemm_split_lin_kernel applies
+// (linear-layer addressing, 128-wide tiles of at least 64 rows); returns -1 where it does not (the caller falls back to
+// arith 0). dry: decide only (needs the op's full geometry for arith 1).
+template <int WM_, int WN_, int MF, int NF, int PRO, int EPI>
+static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool dry)
+{
+    if (dry && arith == 0)
+        return 0;
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
     GemmArgs a = a0;
     a.tilesM = (unsigned)((a.M + BM - 1) / BM);
@@ -619,9 +731,16 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
         if constexpr (PRO == PRO_NONE && WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
             if (lin)
             {
-                hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
-                return;
+                if (dry)
+                    return 0;
+                if (arith == 1)
+                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
+                else
+                    hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
+                return 0;
             }
+        if (dry)
+            return -1;
         fprintf(stderr, "demucs_hip: internal error: a K/V plane projection cannot run on this tile (cfg with BM %d, linear addressing %d)\n", BM, (int)lin);
         abort();
     }
@@ -637,32 +756,41 @@ static void launch_split_one(const GemmArgs &a0, hipStream_t s)
             if constexpr (WM_ == 2 && WN_ == 2 && NF == 4 && MF >= 2)
             {
                 static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+                if (arith == 1) // fp16 terms exist on this kernel only
+                {
+                    if (!dry)
+                        hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
+                    return 0;
+                }
                 if (mode == 1)
                 {
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
-                    return;
+                    return 0;
                 }
             }
+            if (arith == 1)
+                return -1;
             hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, true>), dim3(blocks), dim3(256), 0, s, a);
-            return;
+            return 0;
         }
     }
+    if (arith == 1)
+        return -1;
     if constexpr (EPI != EPI_KPL && EPI != EPI_VT)
         hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
+    return 0;
 }
 
 // The MFMA-bound tile families only (plan.h kTileCfgs): 0 / 7 / 15 (2x2 waves, 4 column fragments), 9 / 16 (2 column
 // fragments), 2 / 10 (4x1 waves, 6 column fragments), 3 / 11 (4x1 waves, 3 column fragments, plain convs only).
 // Returns -1 for anything else: the op keeps its fp32 kernel.
-int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry)
+int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry, int arith)
 {
     if (a.M >= (1ll << 31) - 256 || !a.Wb1 || !a.Wb2)
         return -1;
-#define DMX_CASE(cfgid, WM_, WN_, MF, NF, PRO, EPI)          \
-    case (cfgid * 100 + PRO * 10 + EPI):                    \
-        if (!dry)                                           \
-            launch_split_one<WM_, WN_, MF, NF, PRO, EPI>(a, s); \
-        return 0;
+#define DMX_CASE(cfgid, WM_, WN_, MF, NF, PRO, EPI) \
+    case (cfgid * 100 + PRO * 10 + EPI):           \
+        return launch_split_one<WM_, WN_, MF, NF, PRO, EPI>(a, s, arith, dry);
     switch (cfg * 100 + a.pro * 10 + a.epi)
     {
         DMX_CASE(0, 2, 2, 4, 4, PRO_NONE, EPI_LINEAR)

@@ -56,6 +56,7 @@ struct GemmArgs
     float tableScale;
     int Lout, Cout;
     int trS, trOff; // EPI_TRCONV: output position j = trS*p0 + r - trOff (plan.h)
+    const float *rowScale; // fp16-term kernels (GEMM_FP16X3): [M][2] = {2^s, 2^-s} per A row (launch_rowscale), else null
     unsigned short *kvPl; // EPI_KPL / EPI_VT: three bf16 planes, kvPlane elements apart (plan.h IGemm::kv)
     i64 kvPlane;
     int kvCol0, kvT, kvH, kvHs;
@@ -78,7 +79,13 @@ int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
 // linear layers on a 256x128 tile with four waves of 128x64 (igemm_lin256.hip); -1 when the op is not a plain linear layer
 int launch_igemm_lin256(const GemmArgs &a, hipStream_t s, bool dry = false);
 // GEMM_BF16X3 contexts: the same tiles with exact bf16 operand splits on the bf16 matrix pipe (igemm_split.hip); -1 = not available
-int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
+// arith 0: bf16 terms (DMX_GEMM_BF16X3); 1: fp16 terms (DMX_GEMM_FP16X3: Wb1 = the fp16 plane, rowScale set) - exists for the
+// linear-layer kernel only, returns -1 elsewhere; a dry call with arith 1 needs the op's whole geometry in `a`
+int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false, int arith = 0);
+// per-row scales of a linear layer's A operand (rows of K contiguous floats, the addressing of `a`): out[m] = rowscale_of(max |a|)
+void launch_rowscale(const GemmArgs &a, float *out, hipStream_t s);
+// the fp16 three-term split applied to an array under ONE scale 2^sexp: planes [3][n] fp16 bit patterns (unit test of the split)
+void launch_split3h_debug(const float *d_x, i64 n, int sexp, unsigned short *d_planes, hipStream_t s);
 // the kernels' three-term activation split applied to an array: planes [3][n] bf16 bit patterns (unit test of the split)
 void launch_split3_debug(const float *d_x, i64 n, unsigned short *d_planes, hipStream_t s);
 

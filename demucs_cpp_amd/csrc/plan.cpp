@@ -216,7 +216,7 @@ struct Builder
         // 256x128 / four-wave kernel (igemm_lin256.hip; same conditions as its lin256_ok). DMX_LIN256=0 switches it off (A/B).
         {
             const char *e = getenv("DMX_LIN256");
-            const bool splitMode = opts.gemm == GEMM_BF16X3;
+            const bool splitMode = opts.gemm != GEMM_F32;
             // (the operand-split path has no 256x128 form: its linears stay on the tiles igemm_split.hip instantiates)
             const bool on = (!e || atoi(e) != 0) && !splitMode;
             const bool lin = g.pro == PRO_NONE && (g.epi == EPI_LINEAR || g.epi == EPI_SCALE_RES) && g.S1 == 1 && g.pad0 == 0 &&
@@ -487,7 +487,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
     const i64 aKVf = b.alloc((i64)B * tokT * 2 * D), aKVt = b.alloc((i64)B * tokF * 2 * D);
     const i64 aAttF = b.alloc((i64)B * tokF * D), aAttT = b.alloc((i64)B * tokT * D);
     // bf16 operand planes of K and V^T per branch (plane_linear below): three planes of B x tokens x D elements = 1.5 floats each
-    const bool planesOn = opts.kvPlanes && opts.gemm == GEMM_BF16X3 && (D / 8 == 64 || D / 8 == 48) && D % 128 == 0;
+    const bool planesOn = opts.kvPlanes && opts.gemm != GEMM_F32 && (D / 8 == 64 || D / 8 == 48) && D % 128 == 0;
     const i64 planeFloats = ((i64)B * std::max(tokF, tokT) * D * 3 + 1) / 2;
     const i64 aKplF = planesOn ? b.alloc(planeFloats) : -1, aVtF = planesOn ? b.alloc(planeFloats) : -1;
     const i64 aKplT = planesOn ? b.alloc(planeFloats) : -1, aVtT = planesOn ? b.alloc(planeFloats) : -1;
@@ -601,6 +601,16 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         g.y = y, g.ldy = ldy, g.yBatchStride = (i64)rows * ldy;
         g.res = res, g.scale_w = scale, g.rowstat = rowstat;
         b.finish(g, false);
+        // GEMM_FP16X3: the fp16-term arithmetic exists on the linear-layer kernel only (128- / 64-row tiles of the 128-wide
+        // family); an op must take ONE arithmetic at every batch size (batch = singles bitwise), so the quarter-height sibling
+        // (a staged kernel, bf16 terms) is not offered to it
+        if (opts.gemm == GEMM_FP16X3 && g.N % 128 == 0 && g.K % 32 == 0)
+        {
+            if (g.cfg != 0 && g.cfg != 7)
+                g.cfg = 7;
+            g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
+            g.hterms = 1;
+        }
         b.push_gemm(name, stream, g);
     };
     auto layernorm = [&](const std::string &name, int stream, i64 x, i64 y, int rows, const std::string &w,
@@ -643,6 +653,7 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         if (g.cfg != 0 && g.cfg != 7)
             g.cfg = 7;
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
+        g.hterms = opts.gemm == GEMM_FP16X3 ? 1 : 0;
         b.push_gemm(name, stream, g);
     };
 

@@ -117,11 +117,14 @@ struct IGemm
     int trS, trOff;           // EPI_TRCONV: n = (r, co), r < trS; output position j = trS*p0 + r - trOff
                               // (k8/s4 with the 2-sample crop: 4, 2; v3's uncropped k8/s4: 4, 0; k4/s2: 2, 0)
     int cfg;                  // tile configuration index (engine)
-    int split;                // GEMM_BF16X3 contexts (api.cpp split_ok): run on the exact-split bf16 kernel (igemm_split.hip)
+    int split;                // GEMM_BF16X3 / GEMM_FP16X3 contexts (api.cpp split_kind): 1 = run on the exact-split bf16 kernel (igemm_split.hip); 2 = on its fp16-term form
     // EPI_KPL / EPI_VT: A (float offset) of three bf16 planes of B*kvT*(kvH*kvHs) elements each; rows are tokens (P1 = kvT,
     // P0 = 1), kvT a multiple of 64; -1 otherwise
     i64 kv;
     int kvCol0, kvT, kvH, kvHs;
+    // GEMM_FP16X3 plans: this op (a transformer linear layer kept on the 128- / 64-row tiles at every batch size) may take the
+    // fp16-term kernel; every other op of such a plan runs exactly as in a GEMM_BF16X3 plan
+    int hterms = 0;
 };
 
 struct StatsReduce
@@ -350,6 +353,8 @@ enum GemmMode
 {
     GEMM_F32 = 0,    // v_mfma_f32_16x16x4_f32: fp32 operands, one k-ordered fmaf chain per output
     GEMM_BF16X3 = 1, // exact operand splits a = a1 + a2 + a3, w = w1 + w2 (bf16 terms) on the bf16 matrix pipe, fp32 accumulate
+    GEMM_FP16X3 = 2, // opt-in: as GEMM_BF16X3 (same plan), except that the linear layers run with fp16 terms under a per-row
+                     // power-of-two scale where their weights allow (api.cpp split_kind): bounded, not exact
 };
 struct PlanOpts
 {

@@ -85,11 +85,19 @@ extern "C"
      *                   number in the file - of two (w = w1 + w2: exact), and a w is accumulated in fp32 from five exact
      *                   partial products; the dropped a3 w2 is <= 2^-24 |a w|. MI355X's bf16 MFMA
      *                   rate is 16x its fp32 MFMA rate. Ops whose weights are not fp16-exact stay on the fp32 kernels.
-     * dmx_ctx_create uses the process default: DMX_GEMM_BF16X3 unless the environment says DMX_GEMM=f32 (read once), or
-     * what dmx_set_default_gemm set. A
-     * context keeps its mode for life; contexts of both modes may coexist on one model. (No reference counterpart.) */
+     *   DMX_GEMM_FP16X3 OPT-IN, never the default, reported separately by bench.py. As DMX_GEMM_BF16X3, except that the
+     *                   transformer's linear layers take their weights - fp16 numbers in the model files - as ONE exact fp16
+     *                   term and split each activation row, multiplied by a power of two chosen from the row's largest
+     *                   magnitude (it lands in [2^14, 2^15): nothing can overflow), into three fp16 terms: three
+     *                   v_mfma_f32_16x16x32_f16 per product term instead of five bf16 MFMAs. BOUNDED, not exact: an element
+     *                   more than 2^15 times smaller than the largest of its row loses bits, at most 2^-39 of that largest
+     *                   (the fp32 and bf16x3 modes have no such term); batch size and sharding still do not change a bit.
+     * dmx_ctx_create uses the process default: DMX_GEMM_BF16X3 unless the environment says DMX_GEMM=f32 / fp16x3 (read once),
+     * or what dmx_set_default_gemm set. A context keeps its mode for life; contexts of different modes may coexist on one
+     * model. (No reference counterpart.) */
 #define DMX_GEMM_F32 0
 #define DMX_GEMM_BF16X3 1
+#define DMX_GEMM_FP16X3 2
     int dmx_ctx_create_gemm(const dmx_model *m, int64_t segment_samples, int max_batch, int gemm, dmx_ctx **out);
     int dmx_ctx_gemm(const dmx_ctx *c);
     int dmx_default_gemm(void);
@@ -233,6 +241,9 @@ extern "C"
      * function on `device`): x[i] -> planes[0..n), [n..2n), [2n..3n) = a1, a2, a3; host pointers. */
     int64_t dmx_debug_split_weights(const float *w, int64_t n, unsigned short *w1, unsigned short *w2);
     int dmx_debug_split_activations(int device, const float *x, int64_t n, unsigned short *planes);
+    /* the fp16 three-term split of DMX_GEMM_FP16X3 applied to x[i] * 2^scale_exp (|scale_exp| <= 126): planes[0..n), [n..2n),
+     * [2n..3n) = h1, h2, h3 as fp16 bit patterns; host pointers (unit test of the split and of its stated bound) */
+    int dmx_debug_split_activations_fp16(int device, const float *x, int64_t n, int scale_exp, unsigned short *planes);
 
 #ifdef __cplusplus
 }

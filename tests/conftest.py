@@ -32,19 +32,20 @@ def tmp_models(tmp_path_factory):
     return {4: p4, 6: p6, 3: p3}
 
 
-GEMM_MODES = ["f32", "bf16x3"]
+GEMM_MODES = ["f32", "bf16x3", "fp16x3"]
 
 
 @pytest.fixture(scope="module", params=GEMM_MODES)
 def dmx(request):
     """The ctypes binding with the process default GEMM arithmetic set to the parameter: every `-m gpu` test that takes
     this fixture runs once per mode, IN PROCESS (contexts and engines created by the test get the mode; child processes -
-    the CLIs, bench.py - inherit it through DMX_GEMM). f32: fp32 MFMA; bf16x3: exact bf16 operand splits, fp32 accumulate
+    the CLIs, bench.py - inherit it through DMX_GEMM). f32: fp32 MFMA; bf16x3: exact bf16 operand splits, fp32 accumulate;
+    fp16x3 (opt-in mode): as bf16x3, the linear layers with fp16 terms under a per-row scale
     (include/demucs_hip.h DMX_GEMM_*)."""
     from demucs_cpp_amd import binding
 
     assert binding.device_count() >= 1, "no HIP device: the product has no CPU fallback"
-    mode = {"f32": binding.GEMM_F32, "bf16x3": binding.GEMM_BF16X3}[request.param]
+    mode = {"f32": binding.GEMM_F32, "bf16x3": binding.GEMM_BF16X3, "fp16x3": binding.GEMM_FP16X3}[request.param]
     old_mode, old_env = binding.default_gemm(), os.environ.get("DMX_GEMM")
     binding.set_default_gemm(mode)
     os.environ["DMX_GEMM"] = request.param

@@ -638,7 +638,10 @@ extern "C"
             delete it;
             return nullptr;
         }
-        build_plan(it->pm, seg, B, it->pl);
+        PlanOpts opts;
+        if (const char *e = getenv("DMX_INTERP_GEMM")) // tools/plan_dump.py: the tile choices of the split modes (host only)
+            opts.gemm = atoi(e), opts.kvPlanes = opts.gemm != GEMM_F32;
+        build_plan(it->pm, seg, B, it->pl, opts);
         it->W = nullptr;
         return it;
     }

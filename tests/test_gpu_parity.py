@@ -366,7 +366,7 @@ def test_kv_operand_planes_equal_the_fp32_kv_path(ns, dmx, tmp_models, monkeypat
         classes[planes] = {r[0]: r[1] for r in ctx.profile(B, 1)}
         ctx.close()
     names1, names0 = set(classes["1"]), set(classes["0"])
-    if dmx.gemm_mode_name == "bf16x3":
+    if dmx.gemm_mode_name != "f32":
         assert any(n.endswith(".qk") for n in names1) and any(n.endswith("layers.1.k") for n in names1) and any(n.endswith(".v") for n in names1)
         assert not any(n.endswith(".qkv") or n.endswith(".kv") for n in names1)
     else:
@@ -1213,6 +1213,90 @@ def test_gemm_modes_coexist_in_one_process_and_split_error_is_not_worse(tmp_mode
     with pytest.raises(dmx.DmxError):
         dmx.Context(m, 6000, 1, gemm=7)
     m.close()
+
+
+def test_fp16x3_mode_is_opt_in_bounded_and_uses_its_kernels(tmp_models, golden_dir):
+    """DMX_GEMM_FP16X3 (opt-in third mode, never the default): the transformer's linear layers run as `igemm_splith_*` (fp16
+    terms under a per-row power-of-two scale, three MFMAs per product term), everything else as in a bf16x3 context; against
+    the fp64 golden model it must sit in the same rounding-noise band as the fp32 fmaf chain; it coexists with the other modes
+    on one model handle; the process default is never fp16x3 unless asked for."""
+    from demucs_cpp_amd import binding as dmx
+    assert dmx.GEMM_NAMES[dmx.GEMM_FP16X3] == "fp16x3"
+    for key, gname in ((4, "golden_seg_4s.npz"), (6, "golden_seg_6s.npz")):
+        g = np.load(os.path.join(golden_dir, gname))
+        m = dmx.Model(tmp_models[key])
+        cf = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_F32)
+        cb = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_BF16X3)
+        ch = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_FP16X3)
+        assert ch.gemm == dmx.GEMM_FP16X3
+        of, ob, oh = cf.segment(g["mix"]), cb.segment(g["mix"]), ch.segment(g["mix"])
+        assert not np.array_equal(oh, ob) and not np.array_equal(oh, of)
+        ef, eh = pu.relerr(of, g["out"]), pu.relerr(oh, g["out"])
+        assert eh < TOL and eh <= 2.0 * ef + 1e-7, (key, ef, eh)
+        classes = {}
+        for name, k, *_ in ch.profile(1, 1):
+            classes.setdefault(k, []).append(name)
+        hops = [n for k, v in classes.items() if k.startswith("igemm_splith") for n in v]
+        assert any(n.endswith(".linear1") for n in hops) and any(n.endswith(".linear2") for n in hops) and any(n.endswith(".out_proj") for n in hops)
+        assert not any(k.startswith("igemm_splith") for k in {k for _, k, *_ in cb.profile(1, 1)})
+        cf.close(); cb.close(); ch.close(); m.close()
+
+
+def test_fp16_activation_split_and_its_bound_on_the_device():
+    """The fp16 three-term split of DMX_GEMM_FP16X3 on the device, over the whole domain its kernels can meet. The kernels
+    split x = a 2^s with s from the row's largest magnitude (rowscale: it lands in [2^14, 2^15), or below for rows under 2^-112), so
+    |x| < 2^15 always:
+      * 2^-1 <= |x| < 2^15: h1 + h2 + h3 == x exactly (11 + 11 + 2 significand bits);
+      * |x| < 2^-1: |x - (h1 + h2 + h3)| <= 2^-25 (fp16's subnormal spacing is 2^-24), i.e. <= 2^-39 of the row's largest element;
+      * every term finite; |h2| <= 2^-11 |h1|-ish ordering (each remainder at most half an ulp of the term before).
+    And with the scale itself: an array whose largest magnitude is M, split under s = 14 - floor(log2 M), never overflows."""
+    from demucs_cpp_amd import binding as dmx
+    rng = np.random.default_rng(5)
+    def terms(x, sexp=0):
+        p = dmx.split_activations_fp16(x, sexp)
+        return p.view(np.float16).astype(np.float64)
+    # (1) the exact range: random significands in every binade from 2^-1 to 2^15 (exclusive), both signs, + powers of two +- 1 ulp
+    xs = []
+    for e in range(-1, 15):
+        mant = rng.integers(0, 1 << 23, 20000, dtype=np.uint32)
+        bits = ((127 + e) << 23) | mant
+        xs.append(bits.astype(np.uint32).view(np.float32))
+        edge = np.array([2.0 ** e, np.nextafter(np.float32(2.0 ** e), np.float32(4e4)), np.nextafter(np.float32(2.0 ** (e + 1)), np.float32(0))], np.float32)
+        xs.append(edge)
+    x = np.concatenate(xs).astype(np.float32)
+    x = np.concatenate([x, -x])
+    t = terms(x)
+    assert np.isfinite(t).all()
+    assert np.array_equal(t[0] + t[1] + t[2], x.astype(np.float64)), "three fp16 terms must reproduce |x| in [2^-1, 2^15) exactly"
+    assert (np.abs(t[1]) <= np.abs(t[0]) * 2.0 ** -10).all() and (np.abs(t[2]) <= np.maximum(np.abs(t[1]) * 2.0 ** -10, 2.0 ** -24)).all()
+    # (2) below 2^-1: bounded by 2^-25 absolute, down to zero and fp32 denormals
+    small = np.concatenate([(rng.standard_normal(200000) * 10.0 ** rng.uniform(-30, -0.4, 200000)).astype(np.float32),
+                            np.array([0.0, -0.0, 1e-45, -1e-45, 2.0 ** -24, 2.0 ** -25, 2.0 ** -26, 0.49999997], np.float32)])
+    small = small[np.abs(small) < 0.5]
+    t = terms(small)
+    err = np.abs(t[0] + t[1] + t[2] - small.astype(np.float64))
+    assert np.isfinite(t).all() and err.max() <= 2.0 ** -25, err.max()
+    # (3) the row scale (igemm_common.h rowscale_of: s = 14 - floor(log2 max), capped at 126): whatever finite magnitude the
+    # largest element has, the scaled row cannot overflow and keeps the bounds
+    for M in (1e-44, 1e-38, 1e-30, 3.3e-7, 0.75, 1.0, 777.0, 65504.0, 7e9, 1e35, 3.4e38):
+        row = (rng.standard_normal(4096) * np.float64(M) / 8).astype(np.float32)
+        row[17] = M
+        amax = float(np.abs(row).max())
+        bits = int(np.float32(amax).view(np.uint32))
+        sexp = min(14 - (((bits >> 23) & 0xff) - 127), 126)
+        assert -113 <= sexp <= 126
+        t = terms(row, sexp)
+        xs_ = row.astype(np.float64) * 2.0 ** sexp
+        assert np.isfinite(t).all() and np.abs(xs_).max() < 2.0 ** 15
+        err = np.abs(t[0] + t[1] + t[2] - xs_)
+        big = np.abs(xs_) >= 0.5
+        assert (err[big] == 0).all() and err.max() <= 2.0 ** -25, (M, err.max())
+        if sexp < 126:
+            # the largest element sits in [2^14, 2^15): relative to it the loss of any element is <= 2^-25 / 2^14
+            assert np.abs(xs_).max() >= 2.0 ** 14 and err.max() / np.abs(xs_).max() <= 2.0 ** -39
+        else:
+            # rows below 2^-112: the loss in the row's own units is <= 2^-151, under fp32's smallest denormal step
+            assert err.max() * 2.0 ** -126 <= 2.0 ** -151
 
 
 def test_activation_split_is_exact_and_bounded_on_the_device():
