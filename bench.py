@@ -503,6 +503,8 @@ def main():
             "traffic_ratio": None if not traffic else round(traffic / (by / cnt), 3),
             "effective_clock_ghz": clock_ghz, "effective_clock_source": clock_src, "peak_clock_ghz": 2.4,
             "peak_basis": ("fp32 MFMA v_mfma_f32_16x16x4_f32" if peak == PEAK_TFLOPS_FP32_MFMA else
+                           f"fp16 MFMA dense {PEAK_TFLOPS_BF16_MFMA} TFLOP/s (the bf16 rate) / 3 partial products per fp32 term (per-row scaled fp16 terms: bounded, not exact)"
+                           if kname.startswith("igemm_splith") else
                            f"bf16 MFMA dense {PEAK_TFLOPS_BF16_MFMA} TFLOP/s / {round(PEAK_TFLOPS_BF16_MFMA / peak)} exact partial products per fp32 term"),
         }
 

@@ -726,8 +726,8 @@ extern "C" int interp_plan_dump(void *h, char *buf, int cap)
             const IGemm &g = op.g;
             const i64 M = (i64)g.B * g.P1 * g.P0;
             const i64 tiles = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
-            snprintf(line, sizeof(line), "%s %d %lld %d %d %lld %d\n", op.name.c_str(), g.cfg, (long long)M, g.N, g.K, (long long)tiles,
-                     (int)(g.rowstat >= 0));
+            snprintf(line, sizeof(line), "%s %d %lld %d %d %lld %d %d %d\n", op.name.c_str(), g.cfg, (long long)M, g.N, g.K, (long long)tiles,
+                     (int)(g.rowstat >= 0), g.hterms, g.epi);
             all += line;
         }
     if ((int)all.size() + 1 > cap)

@@ -125,6 +125,17 @@ def test_committed_round5_bench_lines():
     # the committed traffic file of this round is the one bench.py will quote from now on
     t = rd("r05_traffic_bf16x3.json")
     assert t["batch"] == 42 and t["gemm"] == "bf16x3" and "igemm_split_128x128" in t["classes"]
+    # the opt-in fp16x3 mode is reported BESIDE the headline (a scalar key of the default line), never as it; a run that asks
+    # for it says so in dtype / gemm_path and prices its dominant class at the three-MFMA peak
+    three = rd("r05_bench_4s_b42_three_modes.json")
+    assert three["config"]["gemm_path"].startswith("bf16x3") and "bf16x3" in three["dtype"] and "fp16x3" not in three["dtype"]
+    assert three["config"]["fp16x3_outputs_finite"] is True and three["config"]["f32_mfma_outputs_finite"] is True
+    assert three["config"]["f32_mfma_xRT"] < three["value"] < three["config"]["fp16x3_xRT"] < 1.15 * three["value"]
+    assert three["roofline"]["kernel"] == "igemm_split_128x128" and abs(three["roofline"]["peak"] - 503.3) < 0.1
+    h = rd("r05_bench_4s_b42_gemm_fp16x3.json")
+    assert h["config"]["gemm_path"].startswith("fp16x3") and "fp16x3" in h["dtype"] and h["config"]["outputs_finite"] is True
+    assert h["roofline"]["kernel"] == "igemm_splith_128x128" and abs(h["roofline"]["peak"] - 2516.6 / 3) < 0.1
+    assert abs(h["value"] - three["config"]["fp16x3_xRT"]) / h["value"] < 0.02 and "bf16x3_xRT" not in h["config"]
 
 
 def test_round2_bench_line_still_parses():

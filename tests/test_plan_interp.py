@@ -183,6 +183,51 @@ def test_tile_choice_keeps_the_column_tiling_at_every_batch_size(ns, interp, tmp
     assert shrunk > 20  # one and two segments per call do use the small tiles
 
 
+@pytest.mark.parametrize("ns", [4, 6])
+def test_fp16x3_plans_give_an_op_one_arithmetic_at_every_batch_size(ns, interp, tmp_models, monkeypatch):
+    """GEMM_FP16X3 plans (plan.cpp; host only): the ops that may take the fp16-term kernel are marked by the PLAN (IGemm::hterms),
+    they are exactly the transformer's linear layers, its K / V plane projections and the 1x1 channel up- / down-samplers around it
+    (one `linear` builder) - the same set at every batch size - and they
+    sit on the 128- / 64-row tiles of the 128-wide family at every batch size (the only tiles igemm_split_lin_kernel has), so an
+    op never changes arithmetic with the number of segments in flight: batch = singles stays bitwise. (First form of the mode:
+    the 1x1 convs of the DConv blocks also qualified as "linear" on some tiles and not on others - caught on the GPU by
+    test_full_size_track_properties.) Everything else is laid out exactly as in a GEMM_BF16X3 plan."""
+    interp.interp_plan_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    interp.interp_create_plan.restype = ctypes.c_void_p
+    interp.interp_create_plan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]
+
+    def dump(mode, b, seg=343980):
+        monkeypatch.setenv("DMX_INTERP_GEMM", str(mode))
+        h = interp.interp_create_plan(tmp_models[ns].encode(), seg, b)
+        buf = ctypes.create_string_buffer(1 << 18)
+        assert interp.interp_plan_dump(h, buf, 1 << 18) > 0
+        interp.interp_free(h)
+        return [ln.split() for ln in buf.value.decode().splitlines()]
+
+    EPI_KPL, EPI_VT = 7, 8
+    marked_ref = None
+    for b in (1, 2, 3, 4, 5, 8, 12, 24, 42, 64):
+        ops2, ops1 = dump(2, b), dump(1, b)
+        assert [o[0] for o in ops2] == [o[0] for o in ops1]
+        marked = [o[0] for o in ops2 if int(o[7])]
+        marked_ref = marked_ref or marked
+        assert marked == marked_ref and len(marked) >= 50
+        for o2, o1 in zip(ops2, ops1):
+            name, cfg, N, K, ht, epi = o2[0], int(o2[1]), int(o2[3]), int(o2[4]), int(o2[7]), int(o2[8])
+            assert int(o1[7]) == 0  # bf16x3 plans never mark anything
+            if ht:
+                assert name.startswith(("crosstransformer.", "channel_")) and cfg in (0, 7) and N % 128 == 0 and K % 32 == 0, (b, o2)
+            else:
+                assert o2[:7] == o1[:7], (b, o2, o1)  # same tile, same everything as the bf16x3 plan
+                assert not name.startswith("crosstransformer.") or epi not in (EPI_KPL, EPI_VT)
+        lin = [o for o in ops2 if o[0].startswith("crosstransformer.") and o[0].rsplit(".", 1)[-1] in ("linear1", "linear2", "out_proj", "qk", "q", "k", "v", "qkv", "kv")]
+        assert lin and all(int(o[7]) for o in lin), [o for o in lin if not int(o[7])]
+    # short segments (no whole 64-key tiles: no planes) keep the marking on the plain projections
+    ops = dump(2, 3, 20000)
+    assert any(int(o[7]) for o in ops) and not any(int(o[8]) in (EPI_KPL, EPI_VT) for o in ops)
+    assert all(int(o[1]) in (0, 7) for o in ops if int(o[7]))
+
+
 def test_tile_choice_counts_workgroups_per_xcd(interp, tmp_models):
     """The igemm tile map deals ROW tiles round-robin to the 8 XCDs (all column tiles of a row tile on one XCD), so the
     cost model counts the workgroups of the busiest XCD: decoder.0.rewrite at 4 segments is 84 x 6 tiles of 128x128 =
