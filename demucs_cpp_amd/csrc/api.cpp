@@ -614,7 +614,7 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
         // per-row scales of the linear layer in flight (launch_rowscale): two floats per A row, one buffer per stream of the plan
         i64 maxM = 0;
         for (const Op &op : p->ops)
-            if (op.kind == OP_IGEMM && op.g.split == 2)
+            if (op.kind == OP_IGEMM && op.g.hterms) // (every op the plan marks, whatever THIS model's weights allow: dmx_ctx_set_model)
                 maxM = std::max(maxM, (i64)op.g.B * op.g.P1 * op.g.P0);
         if (maxM > 0)
             for (int k = 0; k < 2; ++k)

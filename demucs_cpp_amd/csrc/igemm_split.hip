@@ -668,13 +668,23 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const GemmArgs p, float *
         return;
     const int4 ri = row_info(p, m);
     const float *row = p.X + (i64)ri.x * p.xBS + ((i64)ri.y * p.L0 + (i64)ri.z * p.stride0) * p.Cin;
-    float mx = 0.f;
-    for (int k = l15 * 4; k < p.K; k += 64)
-    {
+    // (fmaxf ignores NaN operands: a NaN element still poisons its products through the split; an inf row maximum gives 2^-114.
+    // A maximum does not depend on the order it is taken in: four loads in flight per lane, same bits as one)
+    float m4[4] = {0.f, 0.f, 0.f, 0.f};
+    auto take = [&](int j, int k) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(row + k);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        // (fmaxf ignores NaN operands: a NaN element still poisons its products through the split; an inf row maximum gives 2^-100)
+        m4[j] = fmaxf(fmaxf(m4[j], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    };
+    int k = l15 * 4;
+    for (; k + 192 < p.K; k += 256)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            take(j, k + 64 * j);
     }
+    for (; k < p.K; k += 64)
+        take(0, k);
+    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1)
         mx = fmaxf(mx, __shfl_xor(mx, off));

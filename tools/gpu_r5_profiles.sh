@@ -53,6 +53,8 @@ fi
 if has fp16; then
   ( timeout 900 python bench.py --gemm fp16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-track 2>&1 | grep '^{' ) > $O/bench_4s_b42_fp16x3.json
   DMX_GEMM=fp16x3 MODEL=4s PBS="42" bash tools/gpu_prof.sh > $O/ops_4s_fp16x3.log 2>&1; cp gpurun_out/profile_ops_4s_b42.tsv $O/ops_4s_b42_fp16x3.tsv
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profh -o r5h -- python $R/bench.py --gemm fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-single --no-track --no-other-gemm 2>&1 | tail -2 ) >> $O/ops_4s_fp16x3.log
+  python tools/pmc_summary.py $(find /tmp/profh -name "*.db" | head -1) --class > $O/kernel_stats_b42_fp16x3_by_class.csv
 fi
 if has erratum; then
   ( timeout 200 tests/_build/pk_f32_erratum 6 0 2>&1 | cut -c1-230 ) > $O/pk_f32_erratum_forms.log
