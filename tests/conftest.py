@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Demucs v3 has no transformer: a DMX_GEMM_FP16X3 context of a v3 model builds the plan of a bf16x3 context and returns the
+    same bits (asserted by test_fp16x3_mode_is_opt_in_bounded_and_uses_its_kernels), so the v3 GPU tests run in that mode only
+    on request (DMX_TEST_ALL_MODES=1: profiles/r05_gpu_tests.txt is such a run) - the driver's GPU step has a time limit."""
+    if os.environ.get("DMX_TEST_ALL_MODES", "0") not in ("", "0"):
+        return
+    skip = pytest.mark.skip(reason="v3 in fp16x3 mode is the bf16x3 plan bit for bit (tested once); DMX_TEST_ALL_MODES=1 runs it anyway")
+    for it in items:
+        cs = getattr(it, "callspec", None)
+        if cs is not None and cs.params.get("dmx") == "fp16x3" and os.path.basename(str(it.fspath)) == "test_gpu_v3.py":
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -1240,6 +1240,14 @@ def test_fp16x3_mode_is_opt_in_bounded_and_uses_its_kernels(tmp_models, golden_d
         assert any(n.endswith(".linear1") for n in hops) and any(n.endswith(".linear2") for n in hops) and any(n.endswith(".out_proj") for n in hops)
         assert not any(k.startswith("igemm_splith") for k in {k for _, k, *_ in cb.profile(1, 1)})
         cf.close(); cb.close(); ch.close(); m.close()
+    # Demucs v3 has no op the plan marks: an fp16x3 context of a v3 model IS a bf16x3 context (tests/conftest.py relies on it)
+    g = np.load(os.path.join(golden_dir, "golden_seg_v3.npz"))
+    m = dmx.Model(tmp_models[3])
+    cb = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_BF16X3)
+    ch = dmx.Context(m, int(g["seg"]), 1, gemm=dmx.GEMM_FP16X3)
+    assert np.array_equal(cb.segment(g["mix"]), ch.segment(g["mix"]))
+    assert [r[:2] for r in cb.profile(1, 1)] == [r[:2] for r in ch.profile(1, 1)]
+    cb.close(); ch.close(); m.close()
 
 
 def test_fp16_activation_split_and_its_bound_on_the_device():

@@ -10,7 +10,7 @@ PARTS=${PARTS:-tests bench ops trace pmc erratum fp16}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 git rev-parse HEAD > $O/head.txt 2>/dev/null || true
 if has tests; then
-  ( DMX_TEST_ERRATUM=1 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 ) > $O/gpu_tests.txt
+  ( DMX_TEST_ERRATUM=1 DMX_TEST_ALL_MODES=1 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 ) > $O/gpu_tests.txt
   ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke ) >> $O/gpu_tests.txt
 fi
 if has bench || has headline; then
