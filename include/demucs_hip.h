@@ -76,7 +76,7 @@ extern "C"
      * allocated once in HBM. segment_samples = 0 selects DMX_SEGMENT_SAMPLES. */
     int dmx_ctx_create(const dmx_model *m, int64_t segment_samples, int max_batch, dmx_ctx **out);
     /* How a context forms the fp32 products of its convolutions / linear layers (the reference does them in fp32 through
-     * Eigen's GEMM, src/conv.hpp:71-524, src/layers.cpp:426-440). Both modes take and return fp32 and keep every other
+     * Eigen's GEMM, src/conv.hpp:71-524, src/layers.cpp:426-440). All modes take and return fp32 and keep every other
      * operation (normalisations, activations, FFTs, reductions) in fp32:
      *   DMX_GEMM_F32    v_mfma_f32_16x16x4_f32: each output is one k-ordered fp32 fmaf chain;
      *   DMX_GEMM_BF16X3 exact operand splits on the bf16 matrix pipe: an activation is the sum of three bf16 terms
