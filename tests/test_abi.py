@@ -168,6 +168,29 @@ def test_weight_split_is_exact_for_every_fp16_value(dmx):
     assert t[0] == np.inf and t[1] == -np.inf and np.isnan(t[2])
 
 
+def test_dmx_gemm_environment_value_selects_the_process_default_and_typos_are_reported():
+    """DMX_GEMM is read once by the first dmx_default_gemm() of a process (no GPU needed): unset / bf16x3 -> DMX_GEMM_BF16X3 (the
+    default), f32 -> DMX_GEMM_F32, fp16x3 -> DMX_GEMM_FP16X3 (opt-in: the ONLY way besides an explicit dmx_ctx_create_gemm /
+    dmx_set_default_gemm to get that mode); anything else is named on stderr and the default is used - a typo must not silently
+    select another arithmetic."""
+    import subprocess
+    import sys
+
+    code = "from demucs_cpp_amd import binding as b; print('MODE', b.default_gemm(), b.GEMM_NAMES[b.default_gemm()])"
+    for val, want, warn in ((None, 1, False), ("", 1, False), ("bf16x3", 1, False), ("f32", 0, False), ("fp16x3", 2, False),
+                            ("fp16", 1, True), ("BF16X3", 1, True), ("fp32", 1, True)):
+        env = dict(os.environ)
+        env.pop("DMX_GEMM", None)
+        if val is not None:
+            env["DMX_GEMM"] = val
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert f"MODE {want} " in r.stdout, (val, r.stdout)
+        assert ("is not one of {f32, bf16x3, fp16x3}" in r.stderr) == warn, (val, r.stderr)
+        if warn:
+            assert f"DMX_GEMM={val}" in r.stderr
+
+
 def test_every_environment_switch_of_the_product_is_documented():
     """INTEGRATION.md's environment table names every DMX_* variable the library, the shim and the CLIs read."""
     import re
