@@ -219,6 +219,16 @@ static int split_kind_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g
 }
 static int split_kind(const dmx_ctx *c, const IGemm &g) { return split_kind_model(c, c->m, g); }
 
+// a failed upload leaves nothing on the device (the caller drops the half-built model without calling dmx_model_free)
+static int upload_failed(dmx_model *m, hipError_t e)
+{
+    for (void *p : {(void *)m->dW, (void *)m->dWb, (void *)m->dWh})
+        if (p)
+            (void)hipFree(p);
+    m->dW = nullptr, m->dWb = nullptr, m->dWh = nullptr;
+    return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
+}
+
 int dmx_model_upload(dmx_model *m, const float *blob)
 {
     HIPCHK(hipSetDevice(m->device));
@@ -229,11 +239,7 @@ int dmx_model_upload(dmx_model *m, const float *blob)
     if (e == hipSuccess)
         e = hipMemcpy(m->dW, blob, m->blobFloats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess)
-    {
-        (void)hipFree(m->dW);
-        m->dW = nullptr;
-        return fail(DMX_ERR_HIP, "dmx_model_load: weight upload failed: %s", hipGetErrorString(e));
-    }
+        return upload_failed(m, e);
     {
         // igemm_split.hip: every blob element as two bf16 terms by round-to-nearest splits, w1 = bf16(w), w2 = bf16(w - w1).
         // Exact for fp16-representable values (11 significand bits <= 8 + 8, fp16 subnormals included: bf16 has the fp32
@@ -243,8 +249,11 @@ int dmx_model_upload(dmx_model *m, const float *blob)
         for (size_t i = 0; i < m->blobFloats; ++i)
             if (!dmx_split_weight(blob[i], planes[i], planes[m->blobFloats + 512 + i]))
                 m->inexactW.push_back((i64)i);
-        HIPCHK(hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short)));
-        HIPCHK(hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        e = hipMalloc((void **)&m->dWb, planes.size() * sizeof(unsigned short));
+        if (e == hipSuccess)
+            e = hipMemcpy(m->dWb, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return upload_failed(m, e);
     }
     {
         // DMX_GEMM_FP16X3: every blob element as ONE fp16 number (round to nearest). Exact for everything that comes straight
@@ -258,8 +267,11 @@ int dmx_model_upload(dmx_model *m, const float *blob)
             if (!((float)h == blob[i]))
                 m->inexactH.push_back((i64)i);
         }
-        HIPCHK(hipMalloc((void **)&m->dWh, plane.size() * sizeof(unsigned short)));
-        HIPCHK(hipMemcpy(m->dWh, plane.data(), plane.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        e = hipMalloc((void **)&m->dWh, plane.size() * sizeof(unsigned short));
+        if (e == hipSuccess)
+            e = hipMemcpy(m->dWh, plane.data(), plane.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return upload_failed(m, e);
     }
     return DMX_OK;
 }
