@@ -14,7 +14,7 @@ NOPK := -Xclang -target-feature -Xclang -packed-fp32-ops
 QUIET := 2> >(grep -v "packed-fp32-ops' is not a recognized feature" >&2)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(NOPK)
 LIB := demucs_cpp_amd/lib/libdemucs_hip.so
-OBJS := $(addprefix build/,igemm.o igemm_split.o igemm_lin256.o dgemm.o fft.o misc.o attention.o attention_split.o resample.o v3.o api.o engine.o plan.o model_pack.o)
+OBJS := $(addprefix build/,igemm.o igemm_split.o igemm_lin256.o dgemm.o dconv_row.o fft.o misc.o attention.o attention_split.o resample.o v3.o api.o engine.o plan.o model_pack.o)
 
 all: $(LIB) cli oracle interp harness micro
 
@@ -76,7 +76,7 @@ clean:
 # experiment builds: make variant NAME=timing FLAGS="-DDMX_TIMING -DDMX_PIN_LOADS=1"
 variant:
 	@mkdir -p build/$(NAME)
-	for f in igemm igemm_split igemm_lin256 dgemm fft misc attention attention_split resample v3; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
+	for f in igemm igemm_split igemm_lin256 dgemm dconv_row fft misc attention attention_split resample v3; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o & done; \
 	for f in api engine plan model_pack; do $(HIPCC) $(HIPFLAGS) $(FLAGS) -x hip -c $(CSRC)/$$f.cpp -o build/$(NAME)/$$f.o & done; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so build/$(NAME)/*.o
 # one file rebuilt with other flags, the rest of the product's objects unchanged:

@@ -189,8 +189,8 @@ static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
     if (c->gemm == DMX_GEMM_F32 || !m->dWb || igemmSplitOff)
         return false;
     GemmArgs k{};
-    k.pro = g.pro, k.epi = g.epi, k.M = (i64)g.B * g.P1 * g.P0;
-    k.Wb1 = k.Wb2 = m->dWb;
+    fill_gemm_geometry(k, g); // (the K / V plane projections are decided from the whole geometry: linear addressing, 32-bit offsets)
+    k.Wb1 = m->dWb + g.w_w, k.Wb2 = m->dWb + m->blobFloats + 512 + g.w_w; // the planes as launch_op passes them
     if (launch_igemm_split(g.cfg, k, nullptr, true) != 0)
         return false;
     // any inexact element inside [w_w, w_w + Np * Kp)? (the list is computed when the weights are uploaded: the same for the
@@ -255,24 +255,37 @@ int dmx_model_upload(dmx_model *m, const float *blob)
         if (e != hipSuccess)
             return upload_failed(m, e);
     }
+    // DMX_GEMM_FP16X3 (opt-in): every blob element as ONE fp16 number (round to nearest). Exact for everything that comes
+    // straight from the fp16 weight file; the rest is listed here, and an op that touches a listed element keeps bf16 terms
+    // (split_kind). The plane itself is only built when a context of that mode binds the model (dmx_model_fp16_plane).
+    m->inexactH.clear();
+    for (size_t i = 0; i < m->blobFloats; ++i)
+        if (!((float)(_Float16)blob[i] == blob[i]))
+            m->inexactH.push_back((i64)i);
+    return DMX_OK;
+}
+
+int dmx_model_fp16_plane(const dmx_model *m)
+{
+    std::lock_guard<std::mutex> lock(m->hMutex);
+    if (m->dWh)
+        return DMX_OK;
+    HIPCHK(hipSetDevice(m->device));
+    unsigned short *pl = nullptr;
+    const size_t n = m->blobFloats + 1024; // (the same readable, finite tail as the other planes)
+    HIPCHK(hipMalloc((void **)&pl, n * sizeof(unsigned short)));
+    hipError_t e = hipMemset(pl, 0, n * sizeof(unsigned short));
+    if (e == hipSuccess)
     {
-        // DMX_GEMM_FP16X3: every blob element as ONE fp16 number (round to nearest). Exact for everything that comes straight
-        // from the fp16 weight file; the rest is listed, and an op that touches a listed element keeps bf16 terms (split_kind).
-        std::vector<unsigned short> plane(m->blobFloats + 1024, 0);
-        m->inexactH.clear();
-        for (size_t i = 0; i < m->blobFloats; ++i)
-        {
-            const _Float16 h = (_Float16)blob[i];
-            memcpy(&plane[i], &h, 2);
-            if (!((float)h == blob[i]))
-                m->inexactH.push_back((i64)i);
-        }
-        e = hipMalloc((void **)&m->dWh, plane.size() * sizeof(unsigned short));
-        if (e == hipSuccess)
-            e = hipMemcpy(m->dWh, plane.data(), plane.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        if (e != hipSuccess)
-            return upload_failed(m, e);
+        launch_f32_to_f16(m->dW, pl, (i64)m->blobFloats, nullptr); // round to nearest even: the conversion inexactH was listed with
+        e = hipDeviceSynchronize();
     }
+    if (e != hipSuccess)
+    {
+        (void)hipFree(pl);
+        return fail(DMX_ERR_HIP, "fp16 weight plane: %s", hipGetErrorString(e));
+    }
+    m->dWh = pl;
     return DMX_OK;
 }
 
@@ -596,11 +609,23 @@ static int ctx_init(dmx_ctx *c, const dmx_model *m, int64_t segment_samples, int
     c->seg = segment_samples;
     c->maxBatch = max_batch;
     HIPCHK(hipSetDevice(m->device));
+    if (gemm == DMX_GEMM_FP16X3)
+        DMXCHK(dmx_model_fp16_plane(m));
     Plan *p = get_plan(c, max_batch);
     std::string why;
     if (!validate_plan(*p, why))
         return fail(DMX_ERR_ARG, "dmx_ctx_create: unsupported geometry (%s)", why.c_str());
     c->arenaFloats = p->arenaFloats;
+    if (gemm != DMX_GEMM_F32 && m->pm.arch != 3)
+    {
+        // dmx_ctx_set_model may bind a model whose K / V projections take the operand-plane form when this one's do not (the
+        // decision follows the model's weights, get_plan): the arena is sized for the larger layout, planes on
+        Plan q;
+        PlanOpts o;
+        o.gemm = gemm, o.kvPlanes = 1;
+        build_plan(m->pm, c->seg, max_batch, q, o);
+        c->arenaFloats = std::max(c->arenaFloats, q.arenaFloats);
+    }
     // + 1 KB of slack behind the last activation for the same prefetch
     HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->arenaFloats * sizeof(float) + 1024));
     HIPCHK(hipMemset(c->dA, 0, (size_t)c->arenaFloats * sizeof(float) + 1024));
@@ -716,6 +741,11 @@ extern "C" int dmx_ctx_set_model(dmx_ctx *c, const dmx_model *m)
     if (m->device != c->m->device || m->pm.arch != c->m->pm.arch || m->pm.n_sources != c->m->pm.n_sources || m->pm.dim != c->m->pm.dim ||
         m->blobFloats != c->m->blobFloats || m->pm.index != c->m->pm.index)
         return fail(DMX_ERR_ARG, "dmx_ctx_set_model: the model differs in architecture or device from the context's");
+    if (c->gemm == DMX_GEMM_FP16X3)
+    {
+        HIPCHK(hipSetDevice(m->device));
+        DMXCHK(dmx_model_fp16_plane(m));
+    }
     bool sameDecisions = true; // (the lists differ between the models of a bag - derived tensors - without changing any decision)
     if (m->inexactW != c->m->inexactW || m->inexactH != c->m->inexactH)
         for (const auto &kv : c->plans)
@@ -862,6 +892,21 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         if ((g.cfg == kDirectCfg ? launch_dgemm(k, s) : launch_igemm(g.cfg, k, s)) != 0)
             return fail(DMX_ERR_ARG, "internal error: no igemm kernel for op %s (cfg %d pro %d epi %d)", op.name.c_str(), g.cfg, g.pro,
                         g.epi);
+        break;
+    }
+    case OP_DCONV_ROW:
+    {
+        const DconvRow &r = op.dr;
+        DconvRowArgs k{};
+        k.x = a(r.x), k.B = r.B, k.T = r.T, k.F = r.F, k.C = r.C, k.hid = r.hid, k.eps = r.eps, k.zero = A + zeroOff;
+        for (int j = 0; j < 2; ++j)
+        {
+            k.k1w[j] = w(r.k1_w[j]), k.k1b[j] = w(r.k1_b[j]), k.gn1w[j] = w(r.gn1_w[j]), k.gn1b[j] = w(r.gn1_b[j]);
+            k.k2w[j] = w(r.k2_w[j]), k.k2b[j] = w(r.k2_b[j]), k.k2fw[j] = w(r.k2f_w[j]), k.k2fb[j] = w(r.k2f_b[j]);
+            k.gn2w[j] = w(r.gn2_w[j]), k.gn2b[j] = w(r.gn2_b[j]), k.scale[j] = w(r.scale_w[j]);
+        }
+        if (launch_dconv_row(k, s) != 0)
+            return fail(DMX_ERR_ARG, "internal error: no row-resident DConv kernel for op %s (C %d hidden %d T %d)", op.name.c_str(), r.C, r.hid, r.T);
         break;
     }
     case OP_STATS_REDUCE:
@@ -1451,6 +1496,16 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
         kernel = t.split ? "attention_split" : "attention";
         flops = 4.0 * t.B * t.H * (double)t.Tq * t.Tk * t.hs;
         bytes = 4.0 * t.B * t.H * t.hs * (2.0 * t.Tq + 2.0 * t.Tk);
+        break;
+    }
+    case OP_DCONV_ROW:
+    {
+        // the ten ops it replaces, priced as SURVEY 8d prices them (hidden width as packed: rup(hid, 4)); bytes: the row in and out
+        const DconvRow &r = op.dr;
+        const double M = (double)r.B * r.T * r.F, hp = (r.hid + 3) / 4 * 4;
+        kernel = "dconv_row";
+        flops = 2.0 * (2.0 * M * hp * 3.0 * r.C + 2.0 * M * (hp + 2) * hp + 2.0 * M * 2.0 * r.C * hp);
+        bytes = 4.0 * 2.0 * M * r.C;
         break;
     }
     case OP_STATS_REDUCE:

@@ -40,10 +40,15 @@ struct dmx_model
                                    // plane 2 starts at element blobFloats + 512
     std::vector<dmx::i64> inexactW; // blob elements that are NOT the exact sum of their two planes (derived tensors), ascending;
                                     // filled at upload, so replicas on other devices (dmx_model_clone) agree with the original
-    unsigned short *dWh = nullptr; // one fp16 plane of the blob (GEMM_FP16X3 contexts: the linear layers' weights as ONE exact term)
-    std::vector<dmx::i64> inexactH; // blob elements that are not fp16 numbers, ascending (same role as inexactW)
+    // one fp16 plane of the blob (GEMM_FP16X3 contexts: the linear layers' weights as ONE exact term). The mode is opt-in: the
+    // plane is built on the device from dW when the first such context binds the model (dmx_model_fp16_plane), not at upload
+    mutable unsigned short *dWh = nullptr;
+    mutable std::mutex hMutex;
+    std::vector<dmx::i64> inexactH; // blob elements that are not fp16 numbers, ascending (same role as inexactW; listed at upload)
     int device = 0;
 };
+// makes m->dWh exist (idempotent, thread-safe); DMX_OK or an error
+int dmx_model_fp16_plane(const dmx_model *m);
 // uploads `blob` (blobFloats floats) as the weights of `m` on m->device
 int dmx_model_upload(dmx_model *m, const float *blob);
 

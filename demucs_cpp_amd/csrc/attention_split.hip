@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
         auto tilep = [&](int t, auto parTag) {
             constexpr int PAR = decltype(parTag)::value;
             dma_v(t);
+            // the vmcnt(6) below counts on the V pieces being ISSUED before the six K pieces: both are LDS-DMA builtins into
+            // different arrays, which the scheduler may otherwise legally reorder: pinned
+            __builtin_amdgcn_sched_barrier(0);
             dma_k((t + 1) * KT, PAR ^ 1); // beyond the end: a clamped re-read, never used
             f32x4 sT[QF][4];
             scores(PAR, sT);

@@ -722,7 +722,9 @@ void launch_split3h_debug(const float *d_x, i64 n, int sexp, unsigned short *d_p
 template <int WM_, int WN_, int MF, int NF, int PRO, int EPI>
 static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool dry)
 {
-    if (dry && arith == 0)
+    // (the K / V plane projections exist only where linear addressing applies: decided below, in dry mode too, from the op's
+    // whole geometry - api.cpp split_ok fills it)
+    if (dry && arith == 0 && EPI != EPI_KPL && EPI != EPI_VT)
         return 0;
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
     GemmArgs a = a0;
@@ -749,10 +751,8 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                 return 0;
             }
-        if (dry)
-            return -1;
-        fprintf(stderr, "demucs_hip: internal error: a K/V plane projection cannot run on this tile (cfg with BM %d, linear addressing %d)\n", BM, (int)lin);
-        abort();
+        (void)BM;
+        return -1; // dry: get_plan rebuilds the plan in the fp32-K/V form; a real launch: launch_op reports the error
     }
     else if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU))
     {

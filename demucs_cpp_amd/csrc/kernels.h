@@ -73,6 +73,20 @@ struct GemmArgs
 // not in their table
 int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry = false);
 
+// The frequency branch's whole DConv residual branch with the (C, T) row of one (segment, bin) resident on the CU
+// (dconv_row.hip; plan.h OP_DCONV_ROW). Pointers of the two layers (dilation 1, 2) into the packed model.
+struct DconvRowArgs
+{
+    float *x; // [B][T][F][C], in place
+    int B, T, F, C, hid;
+    const float *k1w[2], *k1b[2], *gn1w[2], *gn1b[2], *k2w[2], *k2b[2], *k2fw[2], *k2fb[2], *gn2w[2], *gn2b[2], *scale[2];
+    float eps;
+    const float *zero;
+    int rowsPerXcd; // filled by the launcher
+};
+// -1 when no kernel exists for the shape; dry = availability check only (needs B, T, F, C, hid)
+int launch_dconv_row(const DconvRowArgs &a, hipStream_t s, bool dry = false);
+
 // returns 0, or -1 when the (tile, prologue, epilogue) combination is not instantiated;
 // dry = true only checks availability
 int launch_igemm(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false);
@@ -246,6 +260,8 @@ void launch_track_ola(const float *segOut, int nSeg, int S, i64 seg, i64 stride,
                       int gBase = 0);
 // dst[r*dpitch + i] = src[r*spitch + i], r < rows, i < width (floats)
 void launch_copy_rows(float *dst, i64 dpitch, const float *src, i64 spitch, i64 width, int rows, hipStream_t s);
+// dst[i] = fp16 bit pattern of src[i], round to nearest even (the opt-in fp16 weight plane, api.cpp dmx_model_fp16_plane)
+void launch_f32_to_f16(const float *src, unsigned short *dst, i64 n, hipStream_t s);
 // interleaved <-> planar helpers
 void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream_t s);
 

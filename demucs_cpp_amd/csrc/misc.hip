@@ -433,4 +433,19 @@ void launch_planar_to_interleaved(const float *src, float *dst, i64 n, hipStream
     hipLaunchKernelGGL(planar_to_interleaved_kernel, dim3(gx), dim3(256), 0, s, src, dst, n);
 }
 
+__global__ void f32_to_f16_kernel(const float *src, unsigned short *dst, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        const _Float16 h = (_Float16)src[i];
+        dst[i] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+void launch_f32_to_f16(const float *src, unsigned short *dst, i64 n, hipStream_t s)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+
 } // namespace dmx

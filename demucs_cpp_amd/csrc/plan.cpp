@@ -168,6 +168,18 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi)
     return false;
 }
 
+// dconv_row.hip: C = 48 / 96 with hidden C/8 (v4), C = 48 with hidden C/4 (v3); at most 16 waves x 3 fragments of 16 time
+// steps; the image [tap-product weights | k2 planes | factor planes | constants | reduction scratch | P] within the CU's LDS
+size_t dconv_row_lds_bytes(int C, int hid, int T)
+{
+    if (!((C == 48 && (hid == 6 || hid == 12)) || (C == 96 && hid == 12)) || T < 2 || (T + 15) / 16 > 48)
+        return 0;
+    const int HP = (hid + 3) / 4 * 4, RPL = HP / 4, NP = 3 * hid, PS = (NP + 3) / 4 * 4;
+    const size_t floats = (size_t)NP * (C + 8) + (size_t)RPL * 2 * C * 4 + (size_t)RPL * 16 * 4 + 7 * C + 64 + 128 + (size_t)T * PS;
+    const size_t bytes = floats * sizeof(float);
+    return bytes <= 160 * 1024 ? bytes : 0;
+}
+
 namespace
 {
 struct Builder
@@ -302,6 +314,29 @@ struct Builder
         const int C8 = C / (pm.arch == 3 ? 4 : 8), C8p = rup(C8, 4); // hidden width: compress 8 (v4) / 4 (v3)
         const int G0 = P0 > 1 ? P0 : 1;
         const i64 rows = (i64)P1 * P0;
+        // frequency branch, levels 0 / 1: the whole residual branch as ONE op with the (C, T) row of a bin resident on the CU
+        // (dconv_row.hip). A function of (C, hidden width, T) alone - never of the batch. DMX_DCONV_ROW=0: the op chain (A/B).
+        {
+            const char *e = getenv("DMX_DCONV_ROW");
+            if (P0 > 1 && (!e || atoi(e) != 0) && dconv_row_lds_bytes(C, C8, P1) > 0 && (i64)B * P1 * P0 * C < (1ll << 31))
+            {
+                Op op;
+                op.kind = OP_DCONV_ROW;
+                op.stream = stream;
+                op.name = p + ".dconv";
+                DconvRow &r = op.dr;
+                r.x = y, r.B = B, r.T = P1, r.F = P0, r.C = C, r.hid = C8, r.eps = 1e-5f;
+                for (int j = 0; j < 2; ++j)
+                {
+                    const std::string w = p + ".dconv." + std::to_string(j) + ".";
+                    r.k1_w[j] = W(w + "k1.Wt"), r.k1_b[j] = W(w + "k1.b"), r.gn1_w[j] = W(w + "gn1.w"), r.gn1_b[j] = W(w + "gn1.b");
+                    r.k2_w[j] = W(w + "k2.Wt"), r.k2_b[j] = W(w + "k2.b"), r.k2f_w[j] = W(w + "k2f.Wt"), r.k2f_b[j] = W(w + "k2f.b");
+                    r.gn2_w[j] = W(w + "gn2.w"), r.gn2_b[j] = W(w + "gn2.b"), r.scale_w[j] = W(w + "scale");
+                }
+                pl.ops.push_back(op);
+                return;
+            }
+        }
         for (int j = 0; j < 2; ++j)
         {
             const int d = j == 0 ? 1 : 2;
@@ -912,6 +947,10 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
             Wr(g.rowstat, M * std::max(g.NB, 1) * 2);
         break;
     }
+    case OP_DCONV_ROW:
+        R(op.dr.x, (i64)op.dr.B * op.dr.T * op.dr.F * op.dr.C);
+        Wr(op.dr.x, (i64)op.dr.B * op.dr.T * op.dr.F * op.dr.C);
+        break;
     case OP_STATS_REDUCE:
     {
         const StatsReduce &s = op.sr;

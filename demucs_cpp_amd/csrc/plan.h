@@ -43,6 +43,7 @@ enum OpKind
     OP_GN_ACT,      // GroupNorm apply (+GELU | +GLU (+LayerScale, residual)) with an optional row crop
     OP_LSTM,        // one bidirectional LSTM layer (recurrent part; the input projection is an OP_IGEMM)
     OP_LOCAL_ATTN,  // LocalState attention core (scores + decay + softmax over keys + weighted content)
+    OP_DCONV_ROW,   // the frequency branch's whole DConv residual branch, one (segment, bin) row resident per workgroup
 };
 
 enum Prologue
@@ -251,6 +252,26 @@ struct LocalAttn
     int B, T, H, ld;
 };
 
+// DConv residual branch of the FREQUENCY branch, both layers, in place on x [B][T][F][C]
+// (/root/reference/src/layers.cpp:152-375 with the bins as the batch, src/encdec.cpp:43-45,203-207). Per row (b, f), with
+// X = x[b][.][f][.] (T x C), for layer j = 0, 1 (dilation d = 1, 2):
+//   h  = Conv1d(C -> hid, k3, dilation d, padding d)(X)            weights k1.Wt [16][3C] (k = tap*C + c), k1.b
+//   hn = gelu(GroupNorm(1, hid)(h))                                statistics over hid x T, unbiased variance (Q3); gn1.w / gn1.b
+//   y  = Conv1d(hid -> 2C, 1x1)(hn)                                k2.Wt [2C][16] rows in paired order (model_pack.cpp), k2.b
+//   X += scale * glu(GroupNorm(1, 2C)(y))                          statistics over 2C x T; gn2.w / gn2.b (paired order), scale [C]
+// The GPU kernel (dconv_row.hip) takes the 2C-wide statistics from the factor k2f.Wt / k2f.b (see EPI_STATS_FACT) and keeps
+// the row in registers; this op replaces the ten-op chain K1 / r1 / K2 / r2 / K3 per layer of Builder::dconv where
+// dconv_row_lds_bytes() says a kernel exists.
+struct DconvRow
+{
+    i64 x;
+    int B, T, F, C, hid;
+    i64 k1_w[2], k1_b[2], gn1_w[2], gn1_b[2], k2_w[2], k2_b[2], k2f_w[2], k2f_b[2], gn2_w[2], gn2_b[2], scale_w[2]; // W
+    float eps;
+};
+// LDS bytes of the row kernel's image for (C, hidden width, T); 0 = no kernel for the shape (must match dconv_row.hip)
+size_t dconv_row_lds_bytes(int C, int hid, int T);
+
 struct Tap
 {
     i64 off;
@@ -279,6 +300,7 @@ struct Op
     GnAct ga;
     Lstm lstm;
     LocalAttn la;
+    DconvRow dr;
 };
 
 // geometry of one segment (model.hpp:19-24,618-625 generalised to any length)

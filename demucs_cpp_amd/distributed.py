@@ -33,15 +33,27 @@ def slab_size(n_segments: int, world: int) -> int:
     return (n_segments + world - 1) // world
 
 
-class HipBackend:
-    """Device ops through the C ABI (include/demucs_hip.h) on torch-owned HBM tensors."""
+def strong_ceiling(n_items: int, world: int) -> float:
+    """Best possible strong-scaling efficiency of `n_items` equal items dealt in contiguous balanced ranges: the busiest
+    rank runs ceil(n/world) of them (42 segments over 8 GPUs: 5.25 / 6 = 0.875; the bag's 168 items: 21 / 21 = 1.0)."""
+    return n_items / (world * slab_size(n_items, world))
 
-    def __init__(self, ctx):
+
+class HipBackend:
+    """Device ops through the C ABI (include/demucs_hip.h) on torch-owned HBM tensors. `models`: the bag of
+    cli-apps/demucs_ft.cpp (one context, dmx_ctx_set_model per model), else the context's own model."""
+
+    def __init__(self, ctx, models=None):
         self.ctx = ctx
         self.S = ctx.S
         self.seg = ctx.seg
         self.max_batch = ctx.max_batch
         self.device = torch.device("cuda", ctx.model.device)
+        self.models = models
+
+    def set_model(self, mi: int):
+        if self.models is not None:
+            self.ctx.set_model(self.models[mi])
 
     def geometry(self, n, shift):
         return self.ctx.track_geometry(n, shift)  # (shifted_len, n_segments, stride)
@@ -78,7 +90,7 @@ class HipBackend:
 
 
 def track_infer_sharded(backend, audio_il: torch.Tensor, shift: int, dist=None, rank: int = 0, world: int = 1,
-                        root: int = 0) -> Optional[torch.Tensor]:
+                        root: int = 0, gather=None) -> Optional[torch.Tensor]:
     """audio_il: [n][2] interleaved stereo on the backend's device (same on every rank).
     Returns (S, 2, n) on the root, None elsewhere."""
     n = int(audio_il.shape[0])
@@ -92,7 +104,10 @@ def track_infer_sharded(backend, audio_il: torch.Tensor, shift: int, dist=None, 
         backend.infer_segments(audio_il, stats, shift, mine, local)
     if world > 1:
         gathered = [torch.empty_like(local) for _ in range(world)] if rank == root else None
-        dist.gather(local, gathered, dst=root)
+        if gather is not None:  # (tests: a host-staged gather for process groups without device collectives)
+            gather(local, gathered)
+        else:
+            dist.gather(local, gathered, dst=root)
         if rank != root:
             return None
         # slab r holds segments [r*n_seg/world, (r+1)*n_seg/world) in its first slots -> segment order
@@ -100,3 +115,47 @@ def track_infer_sharded(backend, audio_il: torch.Tensor, shift: int, dist=None, 
     else:
         all_seg = local[:n_seg]
     return backend.overlap_add(all_seg, n_seg, n, shift, stats)
+
+
+def bag_infer_sharded(backend, audio_il: torch.Tensor, shifts: List[int], dist=None, rank: int = 0, world: int = 1, root: int = 0,
+                      gather=None) -> Optional[torch.Tensor]:
+    """The fine-tuned bag (cli-apps/demucs_ft.cpp:221-241: every model over the whole track with its own shift offset, stem i
+    kept from model i) strong-scaled over the ranks: the (model, segment) items, model-major, are dealt in contiguous balanced
+    ranges like the segments of one model (csrc/engine.cpp deals the same list), ONE gather of equal slabs to the root, which
+    overlap-adds every model's segments in segment order and keeps its stem. `gather(local, gathered_list_or_None)`
+    replaces dist.gather (tests: a host-staged gather for backends without device collectives)."""
+    n = int(audio_il.shape[0])
+    M = len(shifts)
+    n_segs = [backend.geometry(n, sh)[1] for sh in shifts]
+    starts = [0]
+    for k in n_segs:
+        starts.append(starts[-1] + k)
+    n_items = starts[-1]
+    S, seg = backend.S, backend.seg
+    stats = backend.stats(audio_il)
+    mine = owned_segments(n_items, rank, world)
+    slab = slab_size(n_items, world)
+    local = torch.zeros((slab, S, 2, seg), device=audio_il.device, dtype=torch.float32)
+    pos = 0
+    for mi in range(M):
+        ids = [i - starts[mi] for i in mine if starts[mi] <= i < starts[mi + 1]]
+        if ids:
+            backend.set_model(mi)
+            backend.infer_segments(audio_il, stats, shifts[mi], ids, local[pos:pos + len(ids)])
+            pos += len(ids)
+    if world > 1:
+        gathered = [torch.empty_like(local) for _ in range(world)] if rank == root else None
+        if gather is not None:
+            gather(local, gathered)
+        else:
+            dist.gather(local, gathered, dst=root)
+        if rank != root:
+            return None
+        all_items = torch.cat([gathered[r][:len(owned_segments(n_items, r, world))] for r in range(world)], dim=0)
+    else:
+        all_items = local[:n_items]
+    out = torch.empty((S, 2, n), device=audio_il.device, dtype=torch.float32)
+    for mi in range(M):
+        t = backend.overlap_add(all_items[starts[mi]:starts[mi + 1]].contiguous(), n_segs[mi], n, shifts[mi], stats)
+        out[mi].copy_(t[mi])
+    return out

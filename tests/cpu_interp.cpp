@@ -583,6 +583,67 @@ struct Interp
             }
     }
 
+    // OP_DCONV_ROW: the unfused definition (plan.h), statistics in double from the formed tensors (no factor)
+    void run_dconv_row(const DconvRow &r)
+    {
+        const int T = r.T, F = r.F, C = r.C, H = r.hid;
+#pragma omp parallel for schedule(static)
+        for (i64 row = 0; row < (i64)r.B * F; ++row)
+        {
+            const int b = (int)(row / F), f = (int)(row % F);
+            auto X = [&](int t, int c) -> float & { return A[(size_t)(r.x + (((i64)b * T + t) * F + f) * C + c)]; };
+            std::vector<float> h((size_t)T * H), y((size_t)T * 2 * C);
+            for (int j = 0; j < 2; ++j)
+            {
+                const int d = j + 1;
+                const float *k1 = W + r.k1_w[j], *k1b = W + r.k1_b[j], *k2 = W + r.k2_w[j], *k2b = W + r.k2_b[j];
+                double s = 0, q = 0;
+                for (int t = 0; t < T; ++t)
+                    for (int n = 0; n < H; ++n)
+                    {
+                        float acc = 0.f;
+                        for (int tap = 0; tap < 3; ++tap)
+                        {
+                            const int ti = t + (tap - 1) * d;
+                            if (ti < 0 || ti >= T)
+                                continue;
+                            for (int c = 0; c < C; ++c)
+                                acc += X(ti, c) * k1[(i64)n * 3 * C + tap * C + c];
+                        }
+                        const float v = acc + k1b[n];
+                        h[(size_t)t * H + n] = v;
+                        s += v, q += (double)v * v;
+                    }
+                double cnt = (double)H * T, mean = s / cnt, var = std::max((q - cnt * mean * mean) / (cnt - 1.0), 0.0);
+                const float m1 = (float)mean, r1 = (float)(1.0 / std::sqrt(var + (double)r.eps));
+                for (int t = 0; t < T; ++t)
+                    for (int n = 0; n < H; ++n)
+                        h[(size_t)t * H + n] = gelu((h[(size_t)t * H + n] - m1) * r1 * W[r.gn1_w[j] + n] + W[r.gn1_b[j] + n]);
+                s = q = 0;
+                for (int t = 0; t < T; ++t)
+                    for (int n = 0; n < 2 * C; ++n)
+                    {
+                        float acc = 0.f;
+                        for (int k = 0; k < H; ++k)
+                            acc += h[(size_t)t * H + k] * k2[(i64)n * 16 + k];
+                        const float v = acc + k2b[n];
+                        y[(size_t)t * 2 * C + n] = v;
+                        s += v, q += (double)v * v;
+                    }
+                cnt = 2.0 * C * T, mean = s / cnt, var = std::max((q - cnt * mean * mean) / (cnt - 1.0), 0.0);
+                const float m2 = (float)mean, r2 = (float)(1.0 / std::sqrt(var + (double)r.eps));
+                for (int t = 0; t < T; ++t)
+                    for (int c = 0; c < C; ++c)
+                    {
+                        const int na = (c / 16) * 32 + c % 16, ng = na + 16; // packed GLU pair (model_pack.cpp paired_row)
+                        const float a = (y[(size_t)t * 2 * C + na] - m2) * r2 * W[r.gn2_w[j] + na] + W[r.gn2_b[j] + na];
+                        const float g = (y[(size_t)t * 2 * C + ng] - m2) * r2 * W[r.gn2_w[j] + ng] + W[r.gn2_b[j] + ng];
+                        X(t, c) += W[r.scale_w[j] + c] * (a * sigmoidf(g));
+                    }
+            }
+        }
+    }
+
     void run(int order = 0)
     {
         for (int idx : schedule(order))
@@ -602,6 +663,7 @@ struct Interp
             case OP_GN_ACT: run_gn_act(op.ga); break;
             case OP_LSTM: run_lstm(op.lstm); break;
             case OP_LOCAL_ATTN: run_local_attn(op.la); break;
+            case OP_DCONV_ROW: run_dconv_row(op.dr); break;
             default: break;
             }
         }

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from demucs_cpp_amd.distributed import owned_segments, slab_size, track_infer_sharded  # noqa: E402
+from demucs_cpp_amd.distributed import bag_infer_sharded, owned_segments, slab_size, strong_ceiling, track_infer_sharded  # noqa: E402
 
 SEG, S, MAX_SHIFT = 4000, 3, 22050
 
@@ -120,3 +120,59 @@ def test_world2_equals_world1_and_identity(n, shift):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert np.array_equal(res, single)  # same segment order on the root => bit-identical
+
+
+class BagBackend(CpuBackend):
+    """the bag's test double: "model" mi scales stem s by (s + 1) * (10 + mi), so the kept stem mi must read (mi + 1) * (10 + mi)"""
+
+    def __init__(self):
+        self.mi = 0
+
+    def set_model(self, mi):
+        self.mi = mi
+
+    def infer_segments(self, audio_il, stats, shift, seg_ids, out):
+        super().infer_segments(audio_il, stats, shift, seg_ids, out)
+        out *= 10 + self.mi
+
+
+def _bag_worker(rank, world, port, n, shifts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    audio = 0.1 * torch.randn((n, 2), generator=g)
+    out = bag_infer_sharded(BagBackend(), audio, shifts, dist=dist, rank=rank, world=world)
+    if rank == 0:
+        q.put(out.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bag_items_sharded_over_world2_equal_world1():
+    """configs[4] (cli-apps/demucs_ft.cpp:221-241): the (model, segment) items, model-major, in contiguous balanced ranges; the
+    root keeps stem mi of model mi. Shift offsets that give the models DIFFERENT segment counts, so that rank boundaries fall
+    inside a model and the per-model bookkeeping is exercised."""
+    n, shifts = 3 * SEG + 777, [4033, 12436, 21000]  # S = 3 stems -> a bag of 3 "models"
+    assert len({CpuBackend().geometry(n, sh)[1] for sh in shifts}) > 1
+    g = torch.Generator().manual_seed(0)
+    audio = 0.1 * torch.randn((n, 2), generator=g)
+    single = bag_infer_sharded(BagBackend(), audio, shifts).numpy()
+    mean = audio.mean(dim=1).mean()
+    for mi in range(S):
+        expect = ((mi + 1) * (10 + mi) * (audio - mean) + mean).t().numpy()
+        assert np.abs(single[mi] - expect).max() < 1e-4
+    assert strong_ceiling(42, 8) == 0.875 and strong_ceiling(168, 8) == 1.0 and strong_ceiling(42, 1) == 1.0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bag_worker, args=(r, 2, port, n, shifts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(res, single)

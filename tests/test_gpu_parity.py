@@ -314,14 +314,17 @@ def test_bench_multi_rank_control_flow_on_one_gpu(model, port):
     bit-identical to a local recomputation. Covers everything of the N > 1 bench path except the RCCL
     transport itself (the sharded track path has its own gloo test on CPU). v3: two PROCESSES issue the
     cooperative LSTM kernel on one GPU - the launches take turns through the process-shared lane (api.cpp), a raised
-    status word would fail the run. ft: the bag's four models per rank and step, one gather per model."""
+    status word would fail the run. ft: the bag's four models per rank and step, one gather per model - and the strong-scaling
+    leg of configs[4]: ONE 4-minute track's 168 (model, segment) items dealt 84 per rank (cli-apps/demucs_ft.cpp:221-241),
+    checked by the root against one rank alone; the line must carry track_strong_xRT / strong_ceiling for the bag."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "2", "--model", model, "--backend", "gloo", "--no-cpu-baseline", "--no-roofline", "--no-single", "--no-track"],
+                        "--batch", "2", "--model", model, "--backend", "gloo", "--no-cpu-baseline", "--no-roofline", "--no-single"]
+                       + ([] if model == "ft" else ["--no-track"]),
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "bit-identical to a local recomputation: True" in r.stdout
@@ -330,6 +333,11 @@ def test_bench_multi_rank_control_flow_on_one_gpu(model, port):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["outputs_finite"] and d["scaling"] == "weak"
     assert d["config"]["models"] == (4 if model == "ft" else 1)
+    if model == "ft":
+        assert "strong-scaled track (168 items) bit-identical to one rank alone: True" in r.stdout
+        c = d["config"]
+        assert c["track_strong_xRT"] > 0 and c["track_strong_items"] == 168 and c["track_strong_ranks"] == 2
+        assert c["strong_ceiling"] == 1.0 and c["track_strong_outputs_finite"]
 
 
 @pytest.mark.parametrize("ns", [4, 6])
