@@ -85,3 +85,8 @@ variant1: $(LIB)
 	@mkdir -p build/$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(FLAGS) -c $(CSRC)/$(FILE).hip -o build/$(NAME)/$(FILE).o $(QUIET)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so $(filter-out build/$(FILE).o,$(OBJS)) build/$(NAME)/$(FILE).o -ldl -lpthread
+# the same with the one file taken from another path (generated, instrumented copies: tools/micro/dconv_row_timing.py)
+variant1src: $(LIB)
+	@mkdir -p build/$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS) -I$(CSRC) -c $(SRC) -o build/$(NAME)/$(FILE).o $(QUIET)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so $(filter-out build/$(FILE).o,$(OBJS)) build/$(NAME)/$(FILE).o -ldl -lpthread

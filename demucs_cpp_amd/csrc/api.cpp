@@ -899,12 +899,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         const DconvRow &r = op.dr;
         DconvRowArgs k{};
         k.x = a(r.x), k.B = r.B, k.T = r.T, k.F = r.F, k.C = r.C, k.hid = r.hid, k.eps = r.eps, k.zero = A + zeroOff;
-        for (int j = 0; j < 2; ++j)
-        {
-            k.k1w[j] = w(r.k1_w[j]), k.k1b[j] = w(r.k1_b[j]), k.gn1w[j] = w(r.gn1_w[j]), k.gn1b[j] = w(r.gn1_b[j]);
-            k.k2w[j] = w(r.k2_w[j]), k.k2b[j] = w(r.k2_b[j]), k.k2fw[j] = w(r.k2f_w[j]), k.k2fb[j] = w(r.k2f_b[j]);
-            k.gn2w[j] = w(r.gn2_w[j]), k.gn2b[j] = w(r.gn2_b[j]), k.scale[j] = w(r.scale_w[j]);
-        }
+        k.img[0] = w(r.img_w[0]), k.img[1] = w(r.img_w[1]);
         if (launch_dconv_row(k, s) != 0)
             return fail(DMX_ERR_ARG, "internal error: no row-resident DConv kernel for op %s (C %d hidden %d T %d)", op.name.c_str(), r.C, r.hid, r.T);
         break;

@@ -79,10 +79,12 @@ struct DconvRowArgs
 {
     float *x; // [B][T][F][C], in place
     int B, T, F, C, hid;
-    const float *k1w[2], *k1b[2], *gn1w[2], *gn1b[2], *k2w[2], *k2b[2], *k2fw[2], *k2fb[2], *gn2w[2], *gn2b[2], *scale[2];
+    const float *img[2]; // per layer (dilation 1, 2): the weight image in the kernel's LDS layout (plan.h DconvRowGeo)
     float eps;
     const float *zero;
-    int rowsPerXcd; // filled by the launcher
+    // filled by the launcher
+    int rowsPerXcd;
+    double n1, invN1, invN1m1, n2, invN2, invN2m1; // element counts of the two GroupNorms (hid T, 2C T) and the reciprocals of n, n - 1
 };
 // -1 when no kernel exists for the shape; dry = availability check only (needs B, T, F, C, hid)
 int launch_dconv_row(const DconvRowArgs &a, hipStream_t s, bool dry = false);

@@ -73,6 +73,14 @@ i64 PackedModel::find(const std::string &name) const
     abort();
 }
 
+bool PackedModel::has(const std::string &name) const
+{
+    for (auto &kv : index)
+        if (kv.first == name)
+            return true;
+    return false;
+}
+
 namespace
 {
 struct Packer
@@ -235,7 +243,7 @@ struct Packer
     }
 
     // compress: hidden width = C / compress (8: HTDemucs v4, 4: Demucs v3)
-    void dconv(const std::string &p, int C, int compress = 8)
+    void dconv(const std::string &p, int C, int compress = 8, bool rowimg = false)
     {
         int C8 = C / compress, C8p = rup(C8, 4);
         for (int j = 0; j < 2; ++j)
@@ -345,6 +353,42 @@ struct Packer
             vec_paired(d + "gn2.w", s + "4.weight");
             vec_paired(d + "gn2.b", s + "4.bias");
             vec(d + "scale", s + "6.scale", C);
+            // the same layer as ONE image in the LDS layout of the row-resident kernel (dconv_row.hip; layout: plan.h
+            // DconvRowGeo), for the frequency branch's levels it serves: staging is then a flat copy (LDS-DMA)
+            DconvRowGeo g;
+            if (rowimg && dconv_row_geo(C, C8, g))
+            {
+                std::vector<float> img((size_t)(g.nWp + g.nWk), 0.f);
+                auto at = [&](const std::string &n) { return pm.blob.data() + pm.find(n); };
+                const float *k1 = at(d + "k1.Wt"), *k2 = at(d + "k2.Wt"), *k2f = at(d + "k2f.Wt");
+                static const int tapOf[3] = {1, 0, 2}; // slot group o -> tap (the centre tap first)
+                for (int o = 0; o < 3; ++o)
+                    for (int j = 0; j < C8; ++j)
+                    {
+                        const int hh = j / g.RPL, c = j % g.RPL, q = o * g.RPL + c, row = 16 * (q / 4) + 4 * hh + q % 4;
+                        for (int k = 0; k < C; ++k)
+                            img[(size_t)(row * g.WS + k)] = k1[(i64)j * 3 * C + tapOf[o] * C + k];
+                    }
+                float *wk = img.data() + g.nWp;
+                for (int c = 0; c < g.RPL; ++c)
+                    for (int hh = 0; hh < 4; ++hh)
+                    {
+                        for (int r = 0; r < 2 * C; ++r)
+                            wk[g.oW3 + (c * 2 * C + r) * 4 + hh] = k2[(i64)r * 16 + g.RPL * hh + c];
+                        for (int r = 0; r < 16; ++r)
+                            wk[g.oLf + (c * 16 + r) * 4 + hh] = k2f[(i64)r * 16 + g.RPL * hh + c];
+                    }
+                float *cst = wk + g.oCst;
+                std::copy(at(d + "k2.b"), at(d + "k2.b") + 2 * C, cst);
+                std::copy(at(d + "gn2.w"), at(d + "gn2.w") + 2 * C, cst + 2 * C);
+                std::copy(at(d + "gn2.b"), at(d + "gn2.b") + 2 * C, cst + 4 * C);
+                std::copy(at(d + "scale"), at(d + "scale") + C, cst + 6 * C);
+                std::copy(at(d + "k1.b"), at(d + "k1.b") + 16, cst + 7 * C);
+                std::copy(at(d + "gn1.w"), at(d + "gn1.w") + 16, cst + 7 * C + 16);
+                std::copy(at(d + "gn1.b"), at(d + "gn1.b") + 16, cst + 7 * C + 32);
+                std::copy(at(d + "k2f.b"), at(d + "k2f.b") + 16, cst + 7 * C + 48);
+                std::copy(img.begin(), img.end(), alloc(d + "rowimg", (i64)img.size())); // (alloc may move the blob: copied last)
+            }
         }
     }
 };
@@ -696,7 +740,7 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
             std::string p = std::string(br == 0 ? "encoder." : "tencoder.") + std::to_string(i);
             P.conv(p + ".conv.Wt", p + ".conv.weight", C, br == 0 ? cf : ct, taps8, false);
             P.vec(p + ".conv.b", p + ".conv.bias", rup(C, 16));
-            P.dconv(p, C);
+            P.dconv(p, C, 8, br == 0);
             P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * C, C, tap1, true);
             P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
         }
@@ -713,7 +757,7 @@ bool load_and_pack(const std::string &path, PackedModel &pm, std::string &err)
                     tm.push_back(kh * 3 + kw);
             P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * Cd, Cd, tm, true);
             P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
-            P.dconv(p, Cd);
+            P.dconv(p, Cd, 8, true);
             P.conv_tr(p + ".conv_tr.Wt", p + ".conv_tr.b", p + ".conv_tr.weight", p + ".conv_tr.bias");
         }
         {
@@ -781,7 +825,7 @@ static void pack_v3(PackedModel &pm, const std::map<std::string, Raw> &raw)
             std::string p = std::string(br == 0 ? "encoder." : "tencoder.") + std::to_string(i);
             P.conv(p + ".conv.Wt", p + ".conv.weight", C, br == 0 ? cf : ct, taps8, false);
             P.vec(p + ".conv.b", p + ".conv.bias", rup(C, 16));
-            P.dconv(p, C, 4);
+            P.dconv(p, C, 4, br == 0);
             P.conv(p + ".rewrite.Wt", p + ".rewrite.weight", 2 * C, C, tap1, true);
             P.vec_paired(p + ".rewrite.b", p + ".rewrite.bias");
         }

@@ -168,14 +168,30 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi)
     return false;
 }
 
-// dconv_row.hip: C = 48 / 96 with hidden C/8 (v4), C = 48 with hidden C/4 (v3); at most 16 waves x 3 fragments of 16 time
-// steps; the image [tap-product weights | k2 planes | factor planes | constants | reduction scratch | P] within the CU's LDS
+// dconv_row.hip: C = 48 / 96 with hidden C/8 (v4), C = 48 with hidden C/4 (v3)
+bool dconv_row_geo(int C, int hid, DconvRowGeo &g)
+{
+    if (!((C == 48 && (hid == 6 || hid == 12)) || (C == 96 && hid == 12)))
+        return false;
+    g.HP = (hid + 3) / 4 * 4, g.RPL = g.HP / 4, g.NP = 16 * ((3 * g.RPL + 3) / 4), g.WS = C + 8;
+    g.nWp = (g.NP * g.WS + 255) / 256 * 256;
+    g.oW3 = 0, g.oLf = g.RPL * 2 * C * 4, g.oCst = g.oLf + g.RPL * 16 * 4;
+    g.nWk = (g.oCst + 7 * C + 64 + 255) / 256 * 256;
+    g.resident = C == 48;
+    return true;
+}
+i64 dconv_row_image_floats(int C, int hid)
+{
+    DconvRowGeo g;
+    return dconv_row_geo(C, hid, g) ? (i64)g.nWp + g.nWk : 0;
+}
+// at most 16 waves x 3 fragments of 16 time steps; [K1 sides | K3 sides of both layers | reduction scratch | P0, P2] within the CU's LDS
 size_t dconv_row_lds_bytes(int C, int hid, int T)
 {
-    if (!((C == 48 && (hid == 6 || hid == 12)) || (C == 96 && hid == 12)) || T < 2 || (T + 15) / 16 > 48)
+    DconvRowGeo g;
+    if (!dconv_row_geo(C, hid, g) || T < 2 || (T + 15) / 16 > 48)
         return 0;
-    const int HP = (hid + 3) / 4 * 4, RPL = HP / 4, NP = 3 * hid, PS = (NP + 3) / 4 * 4;
-    const size_t floats = (size_t)NP * (C + 8) + (size_t)RPL * 2 * C * 4 + (size_t)RPL * 16 * 4 + 7 * C + 64 + 128 + (size_t)T * PS;
+    const size_t floats = (size_t)(g.resident ? 2 : 1) * g.nWp + 2 * (size_t)g.nWk + 128 + (size_t)2 * T * g.HP;
     const size_t bytes = floats * sizeof(float);
     return bytes <= 160 * 1024 ? bytes : 0;
 }
@@ -318,7 +334,8 @@ struct Builder
         // (dconv_row.hip). A function of (C, hidden width, T) alone - never of the batch. DMX_DCONV_ROW=0: the op chain (A/B).
         {
             const char *e = getenv("DMX_DCONV_ROW");
-            if (P0 > 1 && (!e || atoi(e) != 0) && dconv_row_lds_bytes(C, C8, P1) > 0 && (i64)B * P1 * P0 * C < (1ll << 31))
+            if (P0 > 1 && (!e || atoi(e) != 0) && dconv_row_lds_bytes(C, C8, P1) > 0 && (i64)B * P1 * P0 * C < (1ll << 31) &&
+                pm.has(p + ".dconv.0.rowimg"))
             {
                 Op op;
                 op.kind = OP_DCONV_ROW;
@@ -332,6 +349,7 @@ struct Builder
                     r.k1_w[j] = W(w + "k1.Wt"), r.k1_b[j] = W(w + "k1.b"), r.gn1_w[j] = W(w + "gn1.w"), r.gn1_b[j] = W(w + "gn1.b");
                     r.k2_w[j] = W(w + "k2.Wt"), r.k2_b[j] = W(w + "k2.b"), r.k2f_w[j] = W(w + "k2f.Wt"), r.k2f_b[j] = W(w + "k2f.b");
                     r.gn2_w[j] = W(w + "gn2.w"), r.gn2_b[j] = W(w + "gn2.b"), r.scale_w[j] = W(w + "scale");
+                    r.img_w[j] = W(w + "rowimg");
                 }
                 pl.ops.push_back(op);
                 return;

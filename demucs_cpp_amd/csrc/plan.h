@@ -267,9 +267,22 @@ struct DconvRow
     i64 x;
     int B, T, F, C, hid;
     i64 k1_w[2], k1_b[2], gn1_w[2], gn1_b[2], k2_w[2], k2_b[2], k2f_w[2], k2f_b[2], gn2_w[2], gn2_b[2], scale_w[2]; // W
+    i64 img_w[2]; // W: the same weights of a layer as ONE image in the row kernel's LDS layout (model_pack.cpp "rowimg")
     float eps;
 };
-// LDS bytes of the row kernel's image for (C, hidden width, T); 0 = no kernel for the shape (must match dconv_row.hip)
+// Layout of the row kernel's per-layer weight image and LDS footprint (must match dconv_row.hip RowGeo; its launcher checks).
+// image = [K1 side: Wp[NP][C + 8]: row 16 (q / 4) + 4 h + q % 4 for slot q = o RPL + c (o = 0 centre tap, 1 tap 0, 2 tap 2; NP = 16
+// ceil(3 RPL / 4)) = k1.Wt[RPL h + c][tap * C + .], unused rows zero | K3 side: W3 planes [RPL][2C][4] =
+// k2.Wt[row][RPL h + c], factor planes [RPL][16][4] = k2f.Wt[n][RPL h + c], constants k2.b | gn2.w | gn2.b (2C each) | scale (C)
+// | k1.b | gn1.w | gn1.b | k2f.b (16 each)], each side padded to whole 256-float pieces.
+struct DconvRowGeo
+{
+    int HP, RPL, NP, WS, nWp, oW3, oLf, oCst, nWk;
+    bool resident; // both layers' K1 sides stay in LDS (C = 48)
+};
+bool dconv_row_geo(int C, int hid, DconvRowGeo &g); // false: no row kernel for (C, hidden width)
+i64 dconv_row_image_floats(int C, int hid);        // nWp + nWk, 0 = no kernel
+// LDS bytes of a workgroup for (C, hidden width, T); 0 = no kernel for the shape
 size_t dconv_row_lds_bytes(int C, int hid, int T);
 
 struct Tap
@@ -320,6 +333,7 @@ struct PackedModel
     std::vector<float> blob;                       // W space
     std::vector<std::pair<std::string, i64>> index; // packed array name -> offset
     i64 find(const std::string &name) const;
+    bool has(const std::string &name) const;
 };
 
 // tile configurations of the igemm kernel (engine.cpp instantiates exactly these)
