@@ -28,7 +28,7 @@ EXPORTS = [
     "dmx_ctx_max_batch", "dmx_ctx_arena_bytes", "dmx_ctx_synchronize", "dmx_ctx_set_stream", "dmx_segment_infer",
     "dmx_segment_infer_device", "dmx_track_infer", "dmx_track_geometry", "dmx_track_stats_device",
     "dmx_track_gather_device", "dmx_track_overlap_add_device", "dmx_debug_tap", "dmx_debug_n_ops",
-    "dmx_debug_profile", "dmx_debug_igemm_timing", "dmx_ctx_set_model", "dmx_model_clone",
+    "dmx_debug_profile", "dmx_ctx_set_model", "dmx_model_clone",
     "dmx_engine_create", "dmx_engine_free", "dmx_engine_n_devices", "dmx_engine_n_models", "dmx_engine_n_sources",
     "dmx_resample_length", "dmx_resample_filter", "dmx_resample_device", "dmx_resample",
     "dmx_ctx_create_gemm", "dmx_ctx_gemm", "dmx_default_gemm", "dmx_set_default_gemm", "dmx_debug_split_weights", "dmx_debug_split_activations", "dmx_debug_split_activations_fp16",
@@ -97,7 +97,6 @@ def lib():
         L.dmx_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, fp]
         L.dmx_debug_n_ops.argtypes = [vp]
         L.dmx_debug_profile.argtypes = [vp, ci, ci, ctypes.c_char_p, ci]
-        L.dmx_debug_igemm_timing.argtypes = [vp, ci, ctypes.c_char_p, fp]
         L.dmx_ctx_set_model.argtypes = [vp, vp]
         L.dmx_engine_create.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, ctypes.POINTER(ci), ci, ci, ci, ctypes.POINTER(vp)]
         L.dmx_engine_free.argtypes = [vp]
@@ -406,8 +405,3 @@ class Engine:
         _chk(lib().dmx_engine_track_infer(self.h, audio.ctypes.data, n, so, out.ctypes.data, LAYOUT_PLANAR, cbp, None))
         return out
 
-
-def igemm_timing(ctx: "Context", batch: int, op_name: str):
-    out = np.zeros(6, np.float64)
-    rc = lib().dmx_debug_igemm_timing(ctx.h, batch, op_name.encode(), out.ctypes.data)
-    return None if rc != 0 else out

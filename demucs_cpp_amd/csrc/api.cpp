@@ -185,8 +185,7 @@ static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
 static bool split_ok(const dmx_ctx *c, const IGemm &g) { return split_ok_model(c, c->m, g); }
 static bool split_ok_model(const dmx_ctx *c, const dmx_model *m, const IGemm &g)
 {
-    static const bool igemmSplitOff = getenv("DMX_IGEMM_SPLIT") && atoi(getenv("DMX_IGEMM_SPLIT")) == 0; // A/B: fp32 GEMMs in split contexts
-    if (c->gemm == DMX_GEMM_F32 || !m->dWb || igemmSplitOff)
+    if (c->gemm == DMX_GEMM_F32 || !m->dWb)
         return false;
     GemmArgs k{};
     fill_gemm_geometry(k, g); // (the K / V plane projections are decided from the whole geometry: linear addressing, 32-bit offsets)
@@ -367,8 +366,7 @@ static Plan *get_plan(dmx_ctx *c, int batch)
     // nothing: if any such op cannot take its exact-split kernel (weights not two-plane exact, kernels switched off) the
     // plan is rebuilt in the fp32-K/V form.
     const bool planesOff = getenv("DMX_KV_PLANES") && atoi(getenv("DMX_KV_PLANES")) == 0; // (read per plan: tests switch it)
-    static const bool attSplitOffEnv = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0;
-    opts.kvPlanes = c->gemm != DMX_GEMM_F32 && !planesOff && !attSplitOffEnv && c->m->pm.arch != 3 ? 1 : 0;
+    opts.kvPlanes = c->gemm != DMX_GEMM_F32 && !planesOff && c->m->pm.arch != 3 ? 1 : 0;
     build_plan(c->m->pm, c->seg, batch, *p, opts);
     if (opts.kvPlanes)
     {
@@ -394,8 +392,7 @@ static Plan *get_plan(dmx_ctx *c, int batch)
         {
             AttnArgs t{};
             t.hs = op.at.hs;
-            static const bool attSplitOff = getenv("DMX_ATT_SPLIT") && atoi(getenv("DMX_ATT_SPLIT")) == 0; // A/B: fp32 attention in split contexts
-            op.at.split = c->gemm != DMX_GEMM_F32 && !attSplitOff && launch_attention_split(t, nullptr, true) == 0 ? 1 : 0;
+            op.at.split = c->gemm != DMX_GEMM_F32 && launch_attention_split(t, nullptr, true) == 0 ? 1 : 0;
         }
     }
     Plan *raw = p.get();
@@ -830,7 +827,6 @@ extern "C" int dmx_ctx_set_stream(dmx_ctx *c, void *hip_stream)
 }
 
 // --------------------------------------------------------------------------- executor
-static unsigned long long *g_dbg = nullptr; // set only by dmx_debug_igemm_timing
 static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
 {
     float *A = c->dA;
@@ -865,7 +861,6 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
         k.kvPlane = (i64)g.B * g.kvT * g.kvH * g.kvHs, k.kvCol0 = g.kvCol0, k.kvT = g.kvT, k.kvH = g.kvH, k.kvHs = g.kvHs;
         k.M = (i64)g.B * g.P1 * g.P0;
         k.zero = A + zeroOff;
-        k.dbg = g_dbg;
         k.Wb1 = k.Wb2 = nullptr;
         k.rowScale = nullptr;
         if (g.split == 2 && c->m->dWh && c->dRowScale[op.stream ? 1 : 0])
@@ -1020,8 +1015,8 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     {
         const LocalAttn &l = op.la;
         // default: the flash attention kernel with the decay penalty (fp32 MFMA; csrc/attention.hip LOC);
-        // DMX_LOCAL_ATTN=valu: the reference-order VALU kernel of csrc/v3.hip (A/B, and what tests/cpu_interp.cpp specifies)
-        static const bool valu = getenv("DMX_LOCAL_ATTN") && std::string(getenv("DMX_LOCAL_ATTN")) == "valu";
+        // shapes it does not cover: the reference-order VALU kernel of csrc/v3.hip
+        const bool valu = false;
         const int hd = l.H / 4;
         int rc = -1;
         if (!valu)
@@ -1625,55 +1620,4 @@ extern "C" int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, 
         report[k] = 0;
     }
     return n;
-}
-
-// Phase timing of one igemm op (library must be built with -DDMX_TIMING): averages over all
-// workgroups of cycles spent in {issue loads, MFMA block, transform+ds_write, addresses,
-// barrier} per K-tile; out[5] = number of K-tiles. Returns 0 or -1.
-extern "C" int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name, double *out)
-{
-    if (!c || !op_name || !out)
-        return -1;
-    (void)hipSetDevice(c->m->device);
-    Plan *p = get_plan(c, batch);
-    for (const Op &op : p->ops)
-        if (op.kind == OP_IGEMM && op.name == op_name)
-        {
-            const IGemm &g = op.g;
-            const i64 M = (i64)g.B * g.P1 * g.P0;
-            if (g.cfg == kDirectCfg)
-                return -1;
-            const i64 nblk = ((M + kTileCfgs[g.cfg].BM - 1) / kTileCfgs[g.cfg].BM) * g.NB;
-            // 8 words per tile, then (timing builds) 2 words per wave of the padded grid: epilogue-internal stamps
-            const i64 gridPad = nblk + 8 * (i64)g.NB + 64;
-            const i64 words = nblk * 8 + gridPad * 8;
-            unsigned long long *d = nullptr;
-            if (hipMalloc((void **)&d, words * 8) != hipSuccess)
-                return -1;
-            (void)hipMemset(d, 0, words * 8);
-            g_dbg = d;
-            launch_op(c, op, c->stream, p->zeroOff);
-            g_dbg = nullptr;
-            (void)hipStreamSynchronize(c->stream);
-            std::vector<unsigned long long> h((size_t)words);
-            (void)hipMemcpy(h.data(), d, words * 8, hipMemcpyDeviceToHost);
-            (void)hipFree(d);
-            if (const char *dump = getenv("DMX_TIMING_DUMP")) // raw per-workgroup records (8 x u64 each)
-                if (FILE *f = fopen(dump, "wb"))
-                {
-                    fwrite(h.data(), 8, h.size(), f);
-                    fclose(f);
-                }
-            for (int i = 0; i < 6; ++i)
-                out[i] = 0;
-            for (i64 b = 0; b < nblk; ++b)
-                for (int i = 0; i < 6; ++i)
-                    out[i] += (double)h[(size_t)(b * 8 + i)];
-            for (int i = 0; i < 6; ++i)
-                out[i] /= (double)nblk;
-            for (int i = 0; i < 5; ++i)
-                out[i] /= out[5] > 0 ? out[5] : 1;
-            return 0;
-        }
-    return -1;
 }

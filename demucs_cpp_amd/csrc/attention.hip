@@ -29,17 +29,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Ablation switches for diagnostic builds (results wrong by construction; never set in the product build)
-#ifndef DMX_ABL_ATT_NOSM
-#define DMX_ABL_ATT_NOSM 0 // no softmax arithmetic
-#endif
-#ifndef DMX_ABL_ATT_NOSTAGE
-#define DMX_ABL_ATT_NOSTAGE 0 // no K/V staging inside the tile loop
-#endif
-#ifndef DMX_ABL_ATT_NOV
-#define DMX_ABL_ATT_NOV 0 // no V fragment reads
-#endif
-
 namespace dmx
 {
 
@@ -244,13 +233,9 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
     float mcur[QF]; // maximum the current tile of fragment f is exponentiated against (set by softmax_pre)
     auto softmax_pre = [&](int t, int f, f32x4 (*sT)[4], auto maskTag) {
         constexpr bool MASK = decltype(maskTag)::value;
-        if (DMX_ABL_ATT_NOSM)
-            return;
         att_softmax_pre<DF, MASK, LOC>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, qrow[f], gq[f]);
     };
     auto softmax_post = [&](int f, f32x4 (*sT)[4]) {
-        if (DMX_ABL_ATT_NOSM)
-            return;
         att_softmax_post(sT[f], lrun[f], mcur[f]);
     };
     // O_f^T += V^T P_f^T : A = V^T[dim = 16d + l15][key = 16kf + 4h4 + c] = one float4 of the V image
@@ -262,10 +247,7 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
 #pragma unroll
             for (int d = 0; d < DF; ++d)
             {
-                if (DMX_ABL_ATT_NOV)
-                    vv[d] = f32x4{qf[0][d].x, qf[0][d].y, qf[0][d].z, qf[0][d].w};
-                else
-                    vv[d] = *reinterpret_cast<const f32x4 *>(&(buf ? Vt1 : Vt0)[4 * kf + h4][(16 * d + l15) ^ (((16 * d + l15) >> 3) & 3)]);
+                vv[d] = *reinterpret_cast<const f32x4 *>(&(buf ? Vt1 : Vt0)[4 * kf + h4][(16 * d + l15) ^ (((16 * d + l15) >> 3) & 3)]);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -294,12 +276,9 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
     // one pipelined step (PAR = t & 1, compile-time): softmax + PV of tile t from sCur, scores of tile t+1 into sNext
     auto step = [&](int t, auto parTag, f32x4 (*sCur)[4], f32x4 (*sNext)[4]) {
         constexpr int PAR = decltype(parTag)::value;
-        if (!DMX_ABL_ATT_NOSTAGE)
-        {
-            load_k((t + 2) * KT, PAR); // beyond the end: clamped re-read, never used. KDIRECT: lands in the buffer of K(t), read last in step t-1
-            if constexpr (!KDIRECT || QF == 1)
-                load_v((t + 1) * KT);
-        }
+        load_k((t + 2) * KT, PAR); // beyond the end: clamped re-read, never used. KDIRECT: lands in the buffer of K(t), read last in step t-1
+        if constexpr (!KDIRECT || QF == 1)
+            load_v((t + 1) * KT);
         // The deferred-maximum test is a (wave-uniform) branch, and the scheduler interleaves only inside a basic
         // block: the MFMAs of the next tile's scores are therefore issued in pieces, one in front of each part
         // of the softmax, so that every block holds matrix work next to its VALU chain.
@@ -325,16 +304,12 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
             // now (its 16 staging registers are not live during the phase above) and has the 128 MFMAs of the
             // PV product to arrive
             __builtin_amdgcn_sched_barrier(0);
-            if (!DMX_ABL_ATT_NOSTAGE)
-                load_v((t + 1) * KT);
+            load_v((t + 1) * KT);
             __builtin_amdgcn_sched_barrier(0);
         }
         pvprod(PAR, sCur);
-        if (!DMX_ABL_ATT_NOSTAGE)
-        {
-            store_k(PAR);
-            store_v(PAR ^ 1);
-        }
+        store_k(PAR);
+        store_v(PAR ^ 1);
         if constexpr (KDIRECT)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -387,7 +362,7 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
 
 void launch_attention(const AttnArgs &a0, hipStream_t s)
 {
-    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
+    constexpr int xcdMap = 1; // all query tiles of one (batch, head) on one XCD
     AttnArgs a = a0;
     a.xcdMap = xcdMap;
     const bool big = att_use_big_shape(a); // 128- or 64-query workgroups (attention_common.h)
@@ -414,7 +389,7 @@ void launch_attention(const AttnArgs &a0, hipStream_t s)
 
 int launch_attention_local(const AttnArgs &a0, hipStream_t s)
 {
-    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
+    constexpr int xcdMap = 1; // all query tiles of one (batch, head) on one XCD
     AttnArgs a = a0;
     a.xcdMap = xcdMap;
     if (!a.decay || (a.hs != 48 && a.hs != 96))

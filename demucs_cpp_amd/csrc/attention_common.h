@@ -144,9 +144,7 @@ inline bool att_use_big_shape(const AttnArgs &a)
 {
     const long wg128 = (long)((a.Tq + 127) / 128) * a.H * a.B, wg64 = (long)((a.Tq + 63) / 64) * a.H * a.B;
     const double costBig = (double)((wg128 + 511) / 512), costSmall = 0.6 * (double)((wg64 + 511) / 512);
-    static const int forceSmall = getenv("DMX_ATT_SMALL") ? atoi(getenv("DMX_ATT_SMALL")) : 0; // experiment: 64-query workgroups everywhere
-    static const int forceBig = getenv("DMX_ATT_BIG") ? atoi(getenv("DMX_ATT_BIG")) : 0;       // experiment: 128-query workgroups everywhere
-    return forceBig || (!forceSmall && wg128 >= 1024 && costBig <= costSmall);
+    return wg128 >= 1024 && costBig <= costSmall;
 }
 
 } // namespace dmx

@@ -38,23 +38,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Ablation mask for diagnostic builds (make variant1 NAME=x FILE=attention_split FLAGS=-DDMX_ATT_ABL=<bits>): results WRONG by
-// construction, 0 in the product.  1: K / V staging without the operand split (three planes = the truncated bits)
-// 2: P without the split   4: no softmax arithmetic
-#ifndef DMX_ATT_ABL
-#define DMX_ATT_ABL 0
-#endif
-
 namespace dmx
 {
-
-__device__ __forceinline__ void att_split3(float x0, float x1, unsigned &h1, unsigned &h2, unsigned &h3, bool ablate)
-{
-    if (ablate)
-        h1 = h2 = h3 = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-    else
-        split3_pk(x0, x1, h1, h2, h3);
-}
 
 __device__ __forceinline__ int swzK(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int swzV(int dim) { return ((dim >> 1) & 1) | (((dim >> 3) & 1) << 1) | (((dim >> 2) & 1) << 2); }
@@ -162,10 +147,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
                 continue;
             const int key = c / KSL, sl = c - key * KSL;
             unsigned h1[4], h2[4], h3[4];
-            att_split3(kreg[i][0][0], kreg[i][0][1], h1[0], h2[0], h3[0], (DMX_ATT_ABL & 1) != 0);
-            att_split3(kreg[i][0][2], kreg[i][0][3], h1[1], h2[1], h3[1], (DMX_ATT_ABL & 1) != 0);
-            att_split3(kreg[i][1][0], kreg[i][1][1], h1[2], h2[2], h3[2], (DMX_ATT_ABL & 1) != 0);
-            att_split3(kreg[i][1][2], kreg[i][1][3], h1[3], h2[3], h3[3], (DMX_ATT_ABL & 1) != 0);
+            split3_pk(kreg[i][0][0], kreg[i][0][1], h1[0], h2[0], h3[0]);
+            split3_pk(kreg[i][0][2], kreg[i][0][3], h1[1], h2[1], h3[1]);
+            split3_pk(kreg[i][1][0], kreg[i][1][1], h1[2], h2[2], h3[2]);
+            split3_pk(kreg[i][1][2], kreg[i][1][3], h1[3], h2[3], h3[3]);
             u32x4(*Kp)[KT][NS] = buf ? Kp1 : Kp0;
             const int sw = sl ^ swzK(key);
             Kp[0][key][sw] = u32x4{h1[0], h1[1], h1[2], h1[3]};
@@ -180,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
         for (int c = 0; c < 4; ++c) // dim 4 vdq + c: keys 4 vkq4 .. +3
         {
             unsigned a1, a2, a3, b1, b2, b3;
-            att_split3(vreg[0][c], vreg[1][c], a1, a2, a3, (DMX_ATT_ABL & 1) != 0);
-            att_split3(vreg[2][c], vreg[3][c], b1, b2, b3, (DMX_ATT_ABL & 1) != 0);
+            split3_pk(vreg[0][c], vreg[1][c], a1, a2, a3);
+            split3_pk(vreg[2][c], vreg[3][c], b1, b2, b3);
             const int dim = 4 * vdq + c;
             const int sw = (4 * vs + vh4) ^ swzV(dim);
             *(reinterpret_cast<u32x2 *>(&Vp[0][dim][sw]) + vhalf) = u32x2{a1, b1};
@@ -284,10 +269,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
             for (int f = 0; f < QF; ++f)
             {
                 unsigned h1[4], h2[4], h3[4];
-                att_split3(sT[f][2 * s][0], sT[f][2 * s][1], h1[0], h2[0], h3[0], (DMX_ATT_ABL & 2) != 0);
-                att_split3(sT[f][2 * s][2], sT[f][2 * s][3], h1[1], h2[1], h3[1], (DMX_ATT_ABL & 2) != 0);
-                att_split3(sT[f][2 * s + 1][0], sT[f][2 * s + 1][1], h1[2], h2[2], h3[2], (DMX_ATT_ABL & 2) != 0);
-                att_split3(sT[f][2 * s + 1][2], sT[f][2 * s + 1][3], h1[3], h2[3], h3[3], (DMX_ATT_ABL & 2) != 0);
+                split3_pk(sT[f][2 * s][0], sT[f][2 * s][1], h1[0], h2[0], h3[0]);
+                split3_pk(sT[f][2 * s][2], sT[f][2 * s][3], h1[1], h2[1], h3[1]);
+                split3_pk(sT[f][2 * s + 1][0], sT[f][2 * s + 1][1], h1[2], h2[2], h3[2]);
+                split3_pk(sT[f][2 * s + 1][2], sT[f][2 * s + 1][3], h1[3], h2[3], h3[3]);
                 pp[f][0] = __builtin_bit_cast(bf16x8, u32x4{h1[0], h1[1], h1[2], h1[3]});
                 pp[f][1] = __builtin_bit_cast(bf16x8, u32x4{h2[0], h2[1], h2[2], h2[3]});
                 pp[f][2] = __builtin_bit_cast(bf16x8, u32x4{h3[0], h3[1], h3[2], h3[3]});
@@ -382,11 +367,8 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const AttnArgs 
 #pragma unroll
         for (int f = 0; f < QF; ++f)
         {
-            if (!(DMX_ATT_ABL & 4))
-            {
-                att_softmax_pre<DF, MASK, false>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, 0, 0.f);
-                att_softmax_post(sT[f], lrun[f], mcur[f]);
-            }
+            att_softmax_pre<DF, MASK, false>(sT[f], o[f], mrun[f], lrun[f], mcur[f], t, h4, p.Tk, 0, 0.f);
+            att_softmax_post(sT[f], lrun[f], mcur[f]);
         }
         __syncthreads();
         pvprod(sT);
@@ -441,7 +423,7 @@ int launch_attention_split(const AttnArgs &a0, hipStream_t s, bool dry)
         return -1;
     if (dry)
         return 0;
-    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1;
+    constexpr int xcdMap = 1; // all query tiles of one (batch, head) on one XCD
     AttnArgs a = a0;
     a.xcdMap = xcdMap;
     const bool big = att_use_big_shape(a); // 128- or 64-query workgroups (attention_common.h): same arithmetic either way

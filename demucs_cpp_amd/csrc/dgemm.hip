@@ -183,11 +183,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs pa, const Fas
 #pragma unroll
         for (int s = 0; s < S1; ++s)
         {
-#ifdef DMX_ABL_DG_SAMETAP // ablation: every tap reads the centre row (what a register sliding window would leave of the tap traffic)
-            const int in1 = p1 * p.stride1;
-#else
             const int in1 = p1 * p.stride1 + s * p.dil1 - p.pad1;
-#endif
             const bool ok1 = rowOk && in1 >= 0 && in1 < p.L1;
             const float *rowp = xb + (i64)(ok1 ? in1 : 0) * rowLen;
 #pragma unroll
@@ -256,19 +252,11 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs pa, const Fas
                 }
                 if (PRO != PRO_NONE && !((st.ok4 >> (s * NV4 + j)) & 1u))
                     v = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef DMX_ABL_DG_NOMFMA // ablation (results wrong): the loads stay, one MFMA per fragment instead of NV4 x 4: what the memory side alone costs
-                asm volatile("" ::"v"(v));
-                if (j == 0)
-#pragma unroll
-                    for (int fj = 0; fj < NF; ++fj)
-                        acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], 0), v[0], acc[fj], 0, 0, 0);
-#else
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int fj = 0; fj < NF; ++fj)
                         acc[fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Bv[fj][s][j], c), v[c], acc[fj], 0, 0, 0);
-#endif
             }
 #pragma unroll
             for (int c = 0; c < RPL; ++c)
@@ -604,9 +592,6 @@ static bool k1_ring_ok(const GemmArgs &a)
            a.seg0 == a.Cin && a.NB == 1 && !a.res;
 }
 
-#ifndef DMX_DG_PIPE
-#define DMX_DG_PIPE -1 // -1: per-shape choice of the launch table; 0/1/2 force one pipeline (experiments)
-#endif
 template <int NF, int S1, int SEG0, int PRO, int EPI, int PIPE_>
 static void launch_d(const GemmArgs &a, hipStream_t s, int chunks = 1)
 {
@@ -614,7 +599,7 @@ static void launch_d(const GemmArgs &a, hipStream_t s, int chunks = 1)
     int blocks = (nfrag + 3) / 4;
     if (blocks > 256 * 8 / chunks)
         blocks = 256 * 8 / chunks; // persistent: 8 workgroups per CU at most, waves stride over fragments
-    constexpr int PIPE = DMX_DG_PIPE >= 0 ? DMX_DG_PIPE : PIPE_;
+    constexpr int PIPE = PIPE_;
     hipLaunchKernelGGL((dgemm_kernel<NF, S1, SEG0, PRO, EPI, PIPE>), dim3(blocks, chunks), dim3(256), 0, s, a, make_fastdiv((unsigned)a.P0),
                        make_fastdiv((unsigned)a.P1));
 }
@@ -651,9 +636,8 @@ int launch_dgemm(const GemmArgs &a, hipStream_t s, bool dry)
         {
             // chunk width: 192 columns keep 12 x K weights in registers (268 / 351 VGPRs: one wave per SIMD) and read the hidden
             // row N / 192 times; 96 columns (6 fragments, ~130 VGPRs: three to four waves per SIMD) read it N / 96 times.
-            // DMX_K3_CHUNK=96|192 for A/B runs; the default is the measured winner (profiles/DESIGN_history_r1-r4.md section 7.6)
-            static const int chunkEnv = getenv("DMX_K3_CHUNK") ? atoi(getenv("DMX_K3_CHUNK")) : 0;
-            const int cw = chunkEnv == 96 || chunkEnv == 192 ? chunkEnv : 96;
+            // 96 is the measured winner (profiles/DESIGN_history_r1-r4.md section 7.6)
+            const int cw = 96;
             GemmArgs c = a; // ONE launch: grid row y = chunk y (the kernel offsets its column-indexed operands by y * N)
             c.N = c.Np = cw;
             const int chunks = a.N / cw;

@@ -24,7 +24,7 @@
 // K loop (IL, the default): tile t is multiplied while tile t+1 goes registers -> LDS and tile t+2 is
 // requested from memory, both in small pieces between the MFMA groups; one barrier per K-tile in the
 // middle of the iteration (see the loop). The plain three-phase loop (loads | MFMA block | ds_write +
-// addresses) is kept behind DMX_IGEMM_IL=0 for A/B measurements. Prologue, epilogue, the linear-layer
+// addresses) remains for the kernels the interleaved loop does not cover. Prologue, epilogue, the linear-layer
 // addressing mode and the loop kind are template parameters (one specialised kernel per combination the
 // plan emits).
 //
@@ -52,25 +52,6 @@
 #endif
 #ifndef DMX_KS1_WAVES
 #define DMX_KS1_WAVES 1 // experiment: min waves per SIMD the KS == 1 kernels are compiled for
-#endif
-
-// Ablation switches for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_ABL_..."`): they remove one
-// ingredient of the interleaved K loop / the epilogue so that its cost can be read off a per-op profile.
-// The results of such a build are WRONG by construction; never set in the product build.
-#ifndef DMX_ABL_NOLOAD
-#define DMX_ABL_NOLOAD 0 // no global loads inside the K loop
-#endif
-#ifndef DMX_ABL_NOSTORE
-#define DMX_ABL_NOSTORE 0 // no ds_write inside the K loop
-#endif
-#ifndef DMX_ABL_NOBAR
-#define DMX_ABL_NOBAR 0 // no barrier inside the K loop
-#endif
-#ifndef DMX_ABL_NOEPI
-#define DMX_ABL_NOEPI 0 // epilogue = one float per lane
-#endif
-#ifndef DMX_ABL_NOADDR
-#define DMX_ABL_NOADDR 0 // no address updates inside the K loop
 #endif
 
 namespace dmx
@@ -264,20 +245,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
     __syncthreads();
     int cur = 0;
     const int l15 = lane & 15, kq = lane >> 4;
-#ifdef DMX_TIMING
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
-#define DMX_TSTAMP(i)                          \
-    do                                         \
-    {                                          \
-        __builtin_amdgcn_sched_barrier(0);     \
-        unsigned long long t_ = clock64();     \
-        tacc[i] += t_ - tprev;                 \
-        tprev = t_;                            \
-        __builtin_amdgcn_sched_barrier(0);     \
-    } while (0)
-#else
-#define DMX_TSTAMP(i)
-#endif
     if constexpr (IL)
     {
         const int fsw = (l15 / RPB) % LPR; // swizzle term of this lane's fragment rows
@@ -315,10 +282,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a0, b0, c);
-                if (!DIRECT && !DMX_ABL_NOSTORE)
+                if (!DIRECT)
                     store_piece(CUR ^ 1, c);
-                if (!DMX_ABL_NOADDR)
-                    addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
+                addr_piece(c); // addresses of tile kt+2 (fetched in the second half)
                 if (c == 1)
                     read_frags(CUR, 1, a1, b1); // fragments of k-chunk 1 arrive behind the rest of chunk 0
                 if (c == 3)
@@ -330,21 +296,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
             // not across the loop back edge), so the wait is explicit.
             if constexpr (DIRECT)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!DMX_ABL_NOBAR)
-                __syncthreads();
+            __syncthreads();
             // k-chunk 1  |  global loads of tile kt+2 (into the registers just written out; DIRECT: into the
             // buffer of tile kt), the first fragments of tile kt+1
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
                 mfma16(a1, b1, c);
-                if (!DMX_ABL_NOLOAD)
-                {
-                    if constexpr (DIRECT)
-                        dload_piece(CUR, c);
-                    else
-                        load_piece(c);
-                }
+                if constexpr (DIRECT)
+                    dload_piece(CUR, c);
+                else
+                    load_piece(c);
                 if (c == 2)
                     read_frags(CUR ^ 1, 0, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -361,7 +323,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
     for (int kt = 0; kt < nk; ++kt)
     {
         issue_loads(); // tile kt+1 (zero page beyond the end: no branch)
-        DMX_TSTAMP(0);
 #pragma unroll
         for (int ch = 0; ch < KS; ++ch)
         {
@@ -382,46 +343,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, KS == 2 || WMF * WNF >= 24 
                     for (int j = 0; j < WNF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(b[j], c), f4c(a[i], c), acc[i][j], 0, 0, 0); // operands swapped: C^T
         }
-        DMX_TSTAMP(1);
         store_tiles(cur ^ 1);
-        DMX_TSTAMP(2);
         compute_addrs();
-        DMX_TSTAMP(3);
         __syncthreads();
-        DMX_TSTAMP(4);
         cur ^= 1;
     }
-#ifdef DMX_TIMING
-    if (p.dbg && tid == 0)
-    {
-        unsigned long long *d = p.dbg + ((i64)tileN * p.tilesM + tileM) * 8;
-        for (int i = 0; i < 5; ++i)
-            d[i] = tacc[i];
-        d[5] = (unsigned long long)nk;
-    }
-#endif
 
-#if DMX_ABL_NOEPI
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-            t += aReg[i][0];
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            t += bReg[i][0];
-        if (m0 + (tid >> 1) < p.M && n0 + 1 < p.N && EPI != EPI_TRCONV && EPI != EPI_STATS_ONLY && EPI != EPI_STATS_FACT)
-            p.Y[(m0 + (tid >> 1)) * p.ldy + (EPI == EPI_GLU || EPI == EPI_GN_GLU_SCALE_RES ? n0 / 2 : n0) + (tid & 1)] = t;
-        else if (t == 123.456f)
-            p.Y[0] = t;
-        return;
-    }
-#endif
     // ------------------------------------------------------------------ epilogue (igemm_common.h)
     igemm_epilogue<WAVES_N, WMF, WNF, EPI, NT>(p, acc, [&](int r) { return rowinfo[r]; }, rsum, m0, n0, tileN, wm, wn, BM);
 }
@@ -430,15 +357,14 @@ template <int WM_, int WN_, int MF, int NF, int KS, int PRO, int EPI>
 static void launch_one(const GemmArgs &a0, hipStream_t s)
 {
     constexpr int BM = WM_ * MF * 16, BN = WN_ * NF * 16;
-    static const int xcdMap = getenv("DMX_XCD_MAP") ? atoi(getenv("DMX_XCD_MAP")) : 1; // 0: plain row-major tiles (A/B)
+    constexpr int xcdMap = 1; // XCD-aware tile map (0 = plain row-major tiles: measured slower, round 2)
     GemmArgs a = a0;
     a.tilesM = (unsigned)((a.M + BM - 1) / BM);
     a.tilesN = (unsigned)((a.N + BN - 1) / BN);
     a.xcdMap = xcdMap;
     a.dP0 = make_fastdiv((unsigned)a.P0), a.dP1 = make_fastdiv((unsigned)a.P1);
     const unsigned blocks = xcdMap ? 8u * ((a.tilesM + 7u) / 8u) * a.tilesN : a.tilesM * a.tilesN;
-    static const int linOn = getenv("DMX_IGEMM_LIN") ? atoi(getenv("DMX_IGEMM_LIN")) : 1;
-    static const int ilOn = getenv("DMX_IGEMM_IL") ? atoi(getenv("DMX_IGEMM_IL")) : 1;
+    constexpr int linOn = 1, ilOn = 1; // linear-layer addressing and the interleaved K loop wherever they apply
     constexpr bool CAN_IL = KS == 2;
     if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU) && KS == 2)
     {

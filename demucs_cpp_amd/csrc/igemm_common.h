@@ -415,9 +415,6 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
                                                int n0, unsigned tileN, int wm, int wn, int BM)
 {
     static_assert(WNF % SSEG == 0, "whole fragments per statistics run");
-#ifdef DMX_TIMING
-    unsigned long long *dmx_epi_ts = reinterpret_cast<unsigned long long *>(p.dbg ? p.dbg + 8ll * p.tilesM * p.tilesN + 2ll * (blockIdx.x * 4 + (threadIdx.x >> 6)) : nullptr); // (debug: per wave)
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int l15 = lane & 15, kq = lane >> 4;
     if constexpr (EPI == EPI_VT)
@@ -637,10 +634,6 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing below loads from global memory
-#ifdef DMX_TIMING
-    if (p.dbg && (threadIdx.x & 63) == 0)
-        dmx_epi_ts[0] = wall_clock64(); // every operand of the epilogue has arrived
-#endif
 
     // ---- pass 2: arithmetic and stores (no global loads: the stores go out back to back)
 #pragma unroll
@@ -649,10 +642,6 @@ __device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x4 (&acc)[W
         const int i = g0 + ig;
         if (i >= WMF)
             break;
-#ifdef DMX_TIMING
-        if (p.dbg && i == 1 && (threadIdx.x & 63) == 0)
-            dmx_epi_ts[1] = wall_clock64(); // first row block stored
-#endif
         const int rl = wm * (WMF * 16) + i * 16 + l15;
         const int4 ri = riA[ig];
         const bool rowOk = ri.w >= 0;

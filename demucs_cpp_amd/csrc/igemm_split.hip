@@ -24,22 +24,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Ablation mask for diagnostic builds (`make variant NAME=x FLAGS="-DDMX_SPLIT_ABL=<bits>"`): removes one ingredient of the K loop
-// so that its cost can be read off a per-op profile. Results of such a build are WRONG by construction; 0 in the product.
-//   1: no operand split (the three planes get the same truncated bits)   2: no ds_write of A   4: no ds_write of B
-//   8: no barrier in the loop   16: no global loads in the loop   32: the kernel returns at once   64: no epilogue (no global stores)   128: no MFMAs   256: no fragment ds_reads
-#ifndef DMX_SPLIT_ABL
-#define DMX_SPLIT_ABL 0
-#endif
-
-#if DMX_SPLIT_ABL & 128
-#define DMX_SPLIT_MFMA(a, b, c, x, y, z) (c)
-#define DMX_SPLIT_MFMA_H(a, b, c, x, y, z) (c)
-#else
-#define DMX_SPLIT_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
-#define DMX_SPLIT_MFMA_H(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
-#endif
-
 namespace dmx
 {
 
@@ -70,8 +54,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     unsigned tileM, tileN;
     if (!tile_of_block(p, tileM, tileN))
         return; // whole workgroup, before any barrier
-    if (DMX_SPLIT_ABL & 32)
-        return;
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
     auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
@@ -107,7 +89,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < BR; ++i)
         bPtr[i] = w.bRowOk[i] ? (bPlaneOf(i) ? p.Wb2 : p.Wb1) + (w.bRow[i] - p.Wt) + bOct * 8 : reinterpret_cast<const unsigned short *>(p.zero);
-    bool inLoop = false; // (ablation builds only)
     // LIN: a row is one contiguous run of K floats, so a staging address is (uniform base) + (32-bit byte offset that
     // advances by one K-tile): the loads take the scalar-base form (global_load ... v_off, s[base]) - one address register
     // per lane instead of a 64-bit pointer pair, one 32-bit add per row and tile. Rows beyond M / columns beyond Np read
@@ -134,8 +115,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
     }
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
-        if ((DMX_SPLIT_ABL & 16) && inLoop)
-            return;
         if constexpr (LIN)
         {
 #pragma unroll
@@ -180,22 +159,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             const f32x4 v = w.transform(aRegS[SET][i], i, (maskHeldS[SET] >> i) & 1u, gWS[SET], gBS[SET]);
             // exact three-way split (igemm_common.h): element k = 4 slane + c sits at bits [16 (k & 7), +16) of its octet
             unsigned h1[2], h2[2], h3[2];
-            if (DMX_SPLIT_ABL & 1)
-            {
-                h1[0] = h2[0] = h3[0] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
-                h1[1] = h2[1] = h3[1] = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
-            }
-            else
-            {
-                split3_pk(v[0], v[1], h1[0], h2[0], h3[0]);
-                split3_pk(v[2], v[3], h1[1], h2[1], h3[1]);
-            }
-            if (DMX_SPLIT_ABL & 2)
-            {
-                if (h1[0] == 0x12345678u && h2[1] == 0x9abcdef0u && h3[0] == 1u) // keeps the values alive without the stores
-                    Ap[0][0][0] = u32x4{h1[0], h1[1], h2[0], h3[1]};
-                continue;
-            }
+            split3_pk(v[0], v[1], h1[0], h2[0], h3[0]);
+            split3_pk(v[2], v[3], h1[1], h2[1], h3[1]);
             const int row = srow + i * RP;
             const int slot = (slane >> 1) ^ swz(row);
             *(reinterpret_cast<u32x2 *>(&Ap[0][row][slot]) + (slane & 1)) = u32x2{h1[0], h1[1]};
@@ -207,12 +172,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
         {
             if (i < b0 || i >= b1e)
                 continue;
-            if (DMX_SPLIT_ABL & 4)
-            {
-                if (bRegS[SET][i][0] == 0x12345678u && bRegS[SET][i][3] == 0x9abcdef0u)
-                    Bp[0][0][0] = bRegS[SET][i];
-                continue;
-            }
             const int row = bRowOf(i);
             Bp[bPlaneOf(i)][row][bOct ^ swz(row)] = bRegS[SET][i];
         }
@@ -276,30 +235,28 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             // smallest terms first; operands swapped (weights as A, activations as B): the accumulator holds C^T
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a3, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a3, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = DMX_SPLIT_MFMA(b2[j], a2, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a2, acc[i][j], 0, 0, 0);
             if (i < SH) // tile kt+1: the other register set -> the other image
                 store_tiles(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1, i * AR / SH, (i + 1) * AR / SH, i * BR / SH, (i + 1) * BR / SH);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = DMX_SPLIT_MFMA(b2[j], a1, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a1, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a2, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a2, acc[i][j], 0, 0, 0);
             if (!LIN && i == WMF - 1)
                 w.compute_addrs(); // addresses of tile kt+3
 #pragma unroll
             for (int j = 0; j < WNF; ++j)
-                acc[i][j] = DMX_SPLIT_MFMA(b1[j], a1, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1, acc[i][j], 0, 0, 0);
             a1 = n1, a2 = n2, a3 = n3;
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(DMX_SPLIT_ABL & 8))
-            __syncthreads();
+        __syncthreads();
     };
-    inLoop = true;
     for (int kt = 0; kt < nk; kt += 2)
     {
         iteration(set0);
@@ -307,20 +264,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const GemmArgs p)
             iteration(set1);
     }
     __syncthreads(); // (rsum aliases the A image)
-    if (DMX_SPLIT_ABL & 64)
-    {
-        // every accumulator stays live (a test of acc[0][0] alone lets the compiler delete 15 of 16 MFMAs: the first
-        // form of this switch "measured" the epilogue at 44 % of the linear layers)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        if (t == 123.456f)
-            p.Y[0] = t;
-        return;
-    }
 
     igemm_epilogue<WAVES_N, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wm, wn, BM);
 }
@@ -360,12 +303,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     unsigned tileM, tileN;
     if (!tile_of_block(p, tileM, tileN))
         return;
-#ifdef DMX_TIMING
-    // per-workgroup timeline (make variant NAME=timing FLAGS=-DDMX_TIMING, dmx_debug_igemm_timing with DMX_TIMING_DUMP=file):
-    // 100 MHz wall clock at entry / loop start / loop end / epilogue issued / stores acknowledged, and where it ran
-    unsigned long long tstamp[5];
-    tstamp[0] = wall_clock64();
-#endif
     const i64 m0 = (i64)tileM * BM;
     const int n0 = (int)tileN * BN;
     auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
@@ -406,11 +343,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     f32x4 aRaw[2][WMF][2];
     u32x4 bReg[2][BR];
     u32x4 aPl[2][WMF][3]; // three 16-bit planes of 8 k each (bf16 or fp16 terms)
-    bool inLoop = false; // (ablation builds only)
     auto issue_loads = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
-        if ((DMX_SPLIT_ABL & 16) && inLoop)
-            return;
 #pragma unroll
         for (int i = 0; i < WMF; ++i)
         {
@@ -430,14 +364,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         constexpr int SET = decltype(setTag)::value, DST = decltype(dstTag)::value;
         const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
         unsigned h1[4], h2[4], h3[4];
-        if (DMX_SPLIT_ABL & 1)
-        {
-            h1[0] = h2[0] = h3[0] = __builtin_amdgcn_perm(__float_as_uint(lo[1]), __float_as_uint(lo[0]), 0x07060302u);
-            h1[1] = h2[1] = h3[1] = __builtin_amdgcn_perm(__float_as_uint(lo[3]), __float_as_uint(lo[2]), 0x07060302u);
-            h1[2] = h2[2] = h3[2] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
-            h1[3] = h2[3] = h3[3] = __builtin_amdgcn_perm(__float_as_uint(hi[3]), __float_as_uint(hi[2]), 0x07060302u);
-        }
-        else if (ARITH)
+        if (ARITH)
         {
             const float sc = aScale[i]; // a power of two: exact
             split3h_pk(lo[0] * sc, lo[1] * sc, h1[0], h2[0], h3[0]);
@@ -468,12 +395,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         {
             if (i < b0 || i >= b1e)
                 continue;
-            if (DMX_SPLIT_ABL & 4)
-            {
-                if (bReg[SET][i][0] == 0x12345678u && bReg[SET][i][3] == 0x9abcdef0u)
-                    Bp[0][0][0] = bReg[SET][i];
-                continue;
-            }
             const int row = bRowOf(i);
             Bp[i % NBP][row][bOct ^ swz(row)] = bReg[SET][i];
         }
@@ -502,7 +423,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     const int fslot = kq ^ swz(l15);
     constexpr int NH = WNF / 4; // column fragments are processed four at a time
     u32x4 b1[NH][4], b2[NH][4]; // weight fragments (b2: the second bf16 plane, ARITH 0 only)
-    bool inLoop2 = false; // (ablation 256: fragments are read in the first iteration only)
     // PAR = kt & 1: the weight image, activation planes and staging register set of tile kt
     auto iteration = [&](auto parTag) {
         constexpr int PAR = decltype(parTag)::value;
@@ -530,23 +450,22 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
                     // EPI_VT: the transposed product (activations as the matrix pipe's A operand): the accumulator holds C, a lane
                     // owns 4 consecutive TOKENS of one channel - the V^T pieces of the attention kernel (igemm_common.h)
                     if constexpr (ARITH == 1 && EPI == EPI_VT)
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA_H(__builtin_bit_cast(f16x8, aPl[PAR][i][plane]), __builtin_bit_cast(f16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
+                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, aPl[PAR][i][plane]), __builtin_bit_cast(f16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
                     else if constexpr (ARITH == 1)
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA_H(__builtin_bit_cast(f16x8, b[j]), __builtin_bit_cast(f16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
+                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[j]), __builtin_bit_cast(f16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
                     else if constexpr (EPI == EPI_VT)
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(__builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), __builtin_bit_cast(bf16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
+                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), __builtin_bit_cast(bf16x8, b[j]), acc[i][h * 4 + j], 0, 0, 0);
                     else
-                        acc[i][h * 4 + j] = DMX_SPLIT_MFMA(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
+                        acc[i][h * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), acc[i][h * 4 + j], 0, 0, 0);
                 }
         };
-        if (!(DMX_SPLIT_ABL & 256) || !inLoop2)
-            read_half(0);
+        read_half(0);
 #pragma unroll
         for (int h = 0; h < NH; ++h)
         {
             // smallest terms first, as in igemm_split_kernel: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (fp16 terms: h3 w, h2 w, h1 w)
             term(h, b1[h], 2);
-            if (h + 1 < NH && (!(DMX_SPLIT_ABL & 256) || !inLoop2))
+            if (h + 1 < NH)
                 read_half(h + 1); // the next half's fragments are in flight during this half's remaining MFMAs
             if (!ARITH)
                 term(h, b2[h], 1);
@@ -562,14 +481,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             term(h, b1[h], 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(DMX_SPLIT_ABL & 8))
-            __syncthreads();
-        inLoop2 = true;
+        __syncthreads();
     };
-    inLoop = true;
-#ifdef DMX_TIMING
-    tstamp[1] = wall_clock64();
-#endif
     for (int kt = 0; kt < nk; kt += 2)
     {
         iteration(set0);
@@ -577,23 +490,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
             iteration(set1);
     }
     __syncthreads(); // (rsum aliases the weight image)
-#ifdef DMX_TIMING
-    tstamp[2] = wall_clock64();
-#endif
-    if (DMX_SPLIT_ABL & 64)
-    {
-        // every accumulator stays live (a test of acc[0][0] alone lets the compiler delete 15 of 16 MFMAs: the first
-        // form of this switch "measured" the epilogue at 44 % of the linear layers)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < WMF; ++i)
-#pragma unroll
-            for (int j = 0; j < WNF; ++j)
-                t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        if (t == 123.456f)
-            p.Y[0] = t;
-        return;
-    }
     if constexpr (ARITH == 1)
     {
         // back to the scale of the activations: acc = 2^s (a . w) -> a . w, a power-of-two factor per ROW (exact unless the product
@@ -624,20 +520,6 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
         }
     }
     igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
-#ifdef DMX_TIMING
-    tstamp[3] = wall_clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tstamp[4] = wall_clock64();
-    if (p.dbg && tid == 0)
-    {
-        unsigned long long *d = p.dbg + ((i64)tileN * p.tilesM + tileM) * 8;
-        for (int i = 0; i < 5; ++i)
-            d[i] = tstamp[i];
-        d[5] = (unsigned long long)nk;
-        d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
-        d[7] = blockIdx.x;
-    }
-#endif
 }
 
 // the kernels' activation split on an array (dmx_debug_split_activations: unit test of the split itself)

@@ -62,7 +62,6 @@ struct GemmArgs
     int kvCol0, kvT, kvH, kvHs;
     i64 M;
     const float *zero; // >= 16 B of zeros, 16-byte aligned: target of out-of-range staging loads
-    unsigned long long *dbg; // per-workgroup phase cycle counters (only read by -DDMX_TIMING builds), else null
     // launch geometry (filled by launch_igemm): 1-D grid, workgroup id -> (row tile, column tile)
     unsigned tilesM, tilesN;
     FastDiv dP0, dP1; // row index m -> (b, p1, p0) without 64-bit divisions (M < 2^31 is checked by the launcher)

@@ -109,18 +109,6 @@ int refine_cfg(int cfg, i64 M, int N, bool stat)
         return (n == 1 ? 1.7 : (double)n) * (double)(kTileCfgs[c].BM * kTileCfgs[c].BN) * (1.0 + 0.03 * depth);
     };
     int best = cfg;
-    if (cfg == 2 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 3 && M >= 256 * 256)
-        return 20;
-    if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 2 && M >= 256 * 256)
-        return 18;
-    if (cfg == 0 && !stat && getenv("DMX_TALL") && atoi(getenv("DMX_TALL")) == 1 && M >= 256 * 256)
-        return 17; // experiment: the double-height tile for launches of at least one full round of 256-row tiles
-    if (const char *e = getenv("DMX_FORCE_HALF")) // experiment: 1 = one halving step for every op, 2 = two
-    {
-        for (int k = atoi(e); k > 0 && half_cfg(best, stat) >= 0; --k)
-            best = half_cfg(best, stat);
-        return best;
-    }
     double bestCost = cost(cfg, 0);
     int depth = 1;
     for (int c = half_cfg(cfg, stat); c >= 0; c = half_cfg(c, stat), ++depth)
@@ -136,10 +124,7 @@ bool direct_available(int N, int S1, int seg0, int pro, int epi)
 {
     // deep-level DConv k3 in column chunks of 192 (dgemm.hip launch_dgemm)
     if (pro == PRO_GN_GELU && epi == EPI_GN_GLU_SCALE_RES && S1 == 1 && (seg0 == 24 || seg0 == 48) && N > 192 && N % 192 == 0)
-    {
-        const char *e = getenv("DMX_K3_CHUNKS"); // 0: keep the LDS-tiled kernel (A/B)
-        return !e || atoi(e) != 0;
-    }
+        return true;
     const int NF = (N + 15) / 16;
     const int key = NF * 1000000 + S1 * 100000 + seg0 * 100 + pro * 10 + epi;
     static const int keys[] = {

@@ -478,10 +478,10 @@ int launch_lstm(const LstmArgs &a, hipStream_t s)
     // tags of an earlier launch must never satisfy a poll of this one
     else if (hipMemsetAsync(a.gran, 0, (size_t)lstm_sync_floats(a.B, a.H) * sizeof(float), s) != hipSuccess)
         return -1;
-    // workgroup shape (env DMX_LSTM_WAVES = 4 | 8, default 4): 4 waves = ONE wave per SIMD, i.e. the 32-cycle fp32 MFMAs of
+    // workgroup shape: 4 waves = ONE wave per SIMD, i.e. the 32-cycle fp32 MFMAs of
     // a step are not shared with a second wave (the recurrence is latency-bound: a step cannot start before the
     // previous one's h has crossed the chip); the price is twice the workgroups polling the same granules
-    static const int nw = getenv("DMX_LSTM_WAVES") ? atoi(getenv("DMX_LSTM_WAVES")) : 4;
+    constexpr int nw = 4;
     if (a.H == 192)
         return nw == 8 ? launch_lstm_t<192, 1, 8>(a, s, x4) : launch_lstm_t<192, 1, 4>(a, s, x4);
     if (a.H == 384)

@@ -234,8 +234,6 @@ extern "C"
      * `report` with lines "name\tkernel\tms_per_launch\talgorithmic_flops\talgorithmic_bytes".
      * Returns the number of ops or -1. Leaves the activations undefined.                   */
     int dmx_debug_profile(dmx_ctx *c, int batch, int reps, char *report, int report_cap);
-    /* cycles per K-tile spent in the 5 phases of one igemm op (-DDMX_TIMING builds only)   */
-    int dmx_debug_igemm_timing(dmx_ctx *c, int batch, const char *op_name, double *out6);
     /* the operand splits of DMX_GEMM_BF16X3, exposed for their unit tests. Weights (pure host function): w[i] -> bf16 bit
      * patterns w1[i], w2[i]; returns the number of elements with w1 + w2 != w. Activations (runs the kernels' own device
      * function on `device`): x[i] -> planes[0..n), [n..2n), [2n..3n) = a1, a2, a3; host pointers. */

@@ -1016,6 +1016,7 @@ def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp
     if dmx.gemm_mode_name != "f32":
         pytest.skip("compares fp32-MFMA tile variants / a kernel both modes share: run once, in the f32 pass")
     import torch
+    monkeypatch.setenv("DMX_DCONV_ROW", "0")  # the op chain: the frequency branch's levels 0 / 1 are otherwise one row-resident op
     m = dmx.Model(tmp_models[which])
     S = m.n_sources
     for B, seg in ((3, SEG_FULL), (2, 9 * 1024 + 2)):
@@ -1032,6 +1033,52 @@ def test_k1_ring_kernels_equal_the_generic_direct_kernel_bitwise(which, dmx, tmp
             ctx.close()
         assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1e-3
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    m.close()
+
+
+@pytest.mark.parametrize("which", [4, 3])
+def test_row_resident_dconv_agrees_with_the_op_chain(which, dmx, tmp_models, monkeypatch):
+    """The frequency branch's DConv of levels 0 / 1 as ONE row-resident op (csrc/dconv_row.hip: a workgroup owns the (C, T) row
+    of a (segment, bin); /root/reference/src/layers.cpp:152-375 with the bins as the batch, src/encdec.cpp:43-45,203-207)
+    against the ten-op chain K1 / r1 / K2 / r2 / K3 it replaces (DMX_DCONV_ROW=0): both are checked against the oracle by the
+    parity tests; here they must agree with each other to fp32 rounding (summation orders differ: taps are summed per tap,
+    the GroupNorm affine is folded) at the taps behind every such op and at the output - full size, a ragged batch, and a
+    short odd frame count (T = 9: one fragment, one wave). The plan must really hold the op (and not hold it when off).
+    v3 (which = 3): hidden width C/4 = 12 at C = 48 runs the row kernel, C = 96 (hidden 24) keeps the chain."""
+    import torch
+    from demucs_cpp_amd.weights import write_synthetic_model  # noqa: F401
+    m = dmx.Model(tmp_models[which])
+    S = m.n_sources
+    for B, seg in ((3, SEG_FULL), (2, 9 * 1024 + 2)):
+        mix = (0.1 * np.random.default_rng(70 + B).standard_normal((B, seg, 2))).astype(np.float32)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DMX_DCONV_ROW", mode)
+            ctx = dmx.Context(m, seg, B)
+            kernels = [r[1] for r in ctx.profile(B, 1)]
+            assert ("dconv_row" in kernels) == (mode == "1"), kernels
+            n_row = kernels.count("dconv_row")
+            assert n_row == (0 if mode == "0" else (4 if which == 4 else 1)), n_row
+            d_mix = torch.from_numpy(mix).cuda()
+            d_out = torch.zeros((B, S, 2, seg), device="cuda", dtype=torch.float32)
+            ctx.segment_device(d_mix.data_ptr(), d_out.data_ptr(), B)
+            ctx.synchronize()
+            taps = {nm: ctx.tap(nm) for nm in (("x_0", "x_1", "dec_2", "dec_3") if which == 4 else ("x_0",))}
+            res[mode] = (d_out.cpu().numpy(), taps)
+            ctx.close()
+        (o1, t1), (o0, t0) = res["1"], res["0"]
+        assert np.isfinite(o1).all() and np.abs(o1).max() > 1e-3
+        for nm in t1:
+            assert np.abs(t1[nm] - t0[nm]).max() <= 2e-5 * np.abs(t0[nm]).max(), nm
+        assert np.abs(o1 - o0).max() <= 2e-5 * np.abs(o0).max()
+        # batch = singles bitwise, through the row kernel (every reduction is inside one workgroup)
+        monkeypatch.setenv("DMX_DCONV_ROW", "1")
+        c1 = dmx.Context(m, seg, 1)
+        d_out1 = torch.zeros((1, S, 2, seg), device="cuda", dtype=torch.float32)
+        c1.segment_device(torch.from_numpy(mix[B - 1:B]).cuda().data_ptr(), d_out1.data_ptr(), 1)
+        c1.synchronize()
+        assert np.array_equal(d_out1.cpu().numpy()[0], o1[B - 1])
+        c1.close()
     m.close()
 
 
