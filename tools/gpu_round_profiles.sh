@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 measurement artefacts, ALL collected by this one script at one commit (copied to profiles/r05_* afterwards):
+# A round's measurement artefacts, ALL collected by this one script at one commit (TAG=r06 -> gpurun_out/r06/*, copied to profiles/r06_* afterwards):
 #   full GPU suite (all three GEMM modes in process, the erratum assertions on), smoke, the bench lines (4s = the headline, 6s,
 #   ft, v3, batch sweep), per-op HIP-event tables, rocprofv3 kernel traces of the bench command in both GEMM modes, the four
 #   PMC passes + effective clock of the default mode (each its own run), the erratum reproducers.
 # Parts: PARTS="tests bench ops trace pmc erratum fp16" (default all but `headline` = the first bench line alone; fp16: bench line and per-op table of the opt-in DMX_GEMM=fp16x3 mode). Bench workload: one 4-minute track = 42 segments per step.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R; O=gpurun_out/r05; mkdir -p $O
+cd $R; TAG=${TAG:-r06}; O=gpurun_out/$TAG; mkdir -p $O
 PARTS=${PARTS:-tests bench ops trace pmc erratum fp16}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 git rev-parse HEAD > $O/head.txt 2>/dev/null || true
@@ -32,8 +32,8 @@ fi
 if has trace; then
   cd /tmp && export TMPDIR=/tmp
   BENCH="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-single --no-track --no-other-gemm"
-  ( timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r5 -- python $R/bench.py $BENCH 2>&1 | tail -3 ) > $R/$O/rocprof.log
-  ( timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof32 -o r5f32 -- python $R/bench.py --gemm f32 $BENCH 2>&1 | tail -3 ) >> $R/$O/rocprof.log
+  ( timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- python $R/bench.py $BENCH 2>&1 | tail -3 ) > $R/$O/rocprof.log
+  ( timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof32 -o tracef32 -- python $R/bench.py --gemm f32 $BENCH 2>&1 | tail -3 ) >> $R/$O/rocprof.log
   cd $R
   db=$(find /tmp/prof -name "*.db" | head -1)
   python tools/pmc_summary.py $db > $O/kernel_stats_b42.csv
@@ -53,7 +53,7 @@ fi
 if has fp16; then
   ( timeout 900 python bench.py --gemm fp16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-track 2>&1 | grep '^{' ) > $O/bench_4s_b42_fp16x3.json
   DMX_GEMM=fp16x3 MODEL=4s PBS="42" bash tools/gpu_prof.sh > $O/ops_4s_fp16x3.log 2>&1; cp gpurun_out/profile_ops_4s_b42.tsv $O/ops_4s_b42_fp16x3.tsv
-  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profh -o r5h -- python $R/bench.py --gemm fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-single --no-track --no-other-gemm 2>&1 | tail -2 ) >> $O/ops_4s_fp16x3.log
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profh -o traceh -- python $R/bench.py --gemm fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-single --no-track --no-other-gemm 2>&1 | tail -2 ) >> $O/ops_4s_fp16x3.log
   python tools/pmc_summary.py $(find /tmp/profh -name "*.db" | head -1) --class > $O/kernel_stats_b42_fp16x3_by_class.csv
 fi
 if has erratum; then
