@@ -90,3 +90,9 @@ variant1src: $(LIB)
 	@mkdir -p build/$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(FLAGS) -I$(CSRC) -c $(SRC) -o build/$(NAME)/$(FILE).o $(QUIET)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so $(filter-out build/$(FILE).o,$(OBJS)) build/$(NAME)/$(FILE).o -ldl -lpthread
+# two files taken from other paths (tools/micro/lin_variants.py: a kernel variant together with the plan choice that exercises it)
+variant2src: $(LIB)
+	@mkdir -p build/$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS) -I$(CSRC) -c $(SRC) -o build/$(NAME)/$(FILE).o $(QUIET)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS) -I$(CSRC) -Iinclude -x hip -c $(SRC2) -o build/$(NAME)/$(FILE2).o $(QUIET)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o demucs_cpp_amd/lib/libdemucs_hip_$(NAME).so $(filter-out build/$(FILE).o build/$(FILE2).o,$(OBJS)) build/$(NAME)/$(FILE).o build/$(NAME)/$(FILE2).o -ldl -lpthread

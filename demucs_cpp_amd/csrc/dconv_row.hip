@@ -154,20 +154,27 @@ __global__ __launch_bounds__(1024, MINW) void dconv_row_kernel(const DconvRowArg
     for (int row = xcdLo + (int)(blockIdx.x >> 3); row < xcdHi; row += slots)
     {
         const int b = row / F, f = row - b * F;
-        float *xrow = p.x + ((i64)b * T * F + f) * C + 4 * ((tid0 & 63) >> 4); // + t * F * C + 16 j
+        // the row's base is uniform (scalar registers); a lane adds a 32-bit byte offset (t F C + 4 h floats: < 2^31 bytes, checked
+        // by the launcher) - one address register per fragment instead of a 64-bit pointer pair. Time steps beyond T re-read the
+        // last valid one: finite values that never reach the statistics or memory (every use is guarded by tOk).
+        char *xrow = reinterpret_cast<char *>(p.x + ((i64)b * T * F + f) * C);
 
-        // ---- x -> registers (MFMA B-operand order), once
+        // ---- x -> registers (MFMA B-operand order), once. (The offsets are functions of the thread id alone; computed from a
+        // laundered copy here and again at the store, they are a few VALU instructions per row instead of 64-bit pairs kept -
+        // and spilled - across the whole row: scratch reloads evicted by the streaming rows were as many HBM bytes as x itself.)
         f32x4 xr[FPW][NJ];
         bool tOk[FPW];
+        int tidl = tid0;
+        asm volatile("" : "+v"(tidl));
 #pragma unroll
         for (int i = 0; i < FPW; ++i)
         {
-            const int t = ((tid0 >> 6) * FPW + i) * 16 + (tid0 & 15);
+            const int t = ((tidl >> 6) * FPW + i) * 16 + (tidl & 15);
             tOk[i] = t < T;
-            const float *src = tOk[i] ? xrow + (i64)t * F * C : p.zero;
+            const unsigned off = ((unsigned)min(t, T - 1) * (unsigned)(F * C) + 4u * ((tidl & 63) >> 4)) * 4u;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                xr[i][j] = *reinterpret_cast<const f32x4 *>(tOk[i] ? src + 16 * j : src);
+                xr[i][j] = *reinterpret_cast<const f32x4 *>(xrow + off + 64 * j);
         }
 
 #pragma unroll 1
@@ -373,14 +380,16 @@ __global__ __launch_bounds__(1024, MINW) void dconv_row_kernel(const DconvRowArg
         }
 
         // ---- x back, once
+        int tids = tid0;
+        asm volatile("" : "+v"(tids));
 #pragma unroll
         for (int i = 0; i < FPW; ++i)
             if (tOk[i])
             {
-                float *dst = xrow + (i64)(((tid0 >> 6) * FPW + i) * 16 + (tid0 & 15)) * F * C;
+                const unsigned off = ((unsigned)(((tids >> 6) * FPW + i) * 16 + (tids & 15)) * (unsigned)(F * C) + 4u * ((tids & 63) >> 4)) * 4u;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    *reinterpret_cast<f32x4 *>(dst + 16 * j) = xr[i][j];
+                    *reinterpret_cast<f32x4 *>(xrow + off + 64 * j) = xr[i][j];
             }
     }
 }
@@ -391,7 +400,7 @@ int launch_dconv_row(const DconvRowArgs &a, hipStream_t s, bool dry)
 {
     constexpr int FPW = 3;
     const int nfrag = (a.T + 15) / 16, nw = (nfrag + FPW - 1) / FPW;
-    if (a.T < 2 || nw > 16 || (i64)a.B * a.T * a.F * a.C >= (1ll << 31))
+    if (a.T < 2 || nw > 16 || (i64)a.B * a.T * a.F * a.C >= (1ll << 31) || (i64)a.T * a.F * a.C * 4 >= (1ll << 32)) // (32-bit byte offsets inside a segment)
         return -1;
     auto go = [&](auto kern, size_t smem, i64 imgFloats) -> int {
         if (smem > 160 * 1024 || smem != dconv_row_lds_bytes(a.C, a.hid, a.T) || imgFloats != dconv_row_image_floats(a.C, a.hid))
