@@ -1465,6 +1465,14 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
                 kernel = splitNames[g.cfg];
             if (g.split == 2) // fp16 terms (+ the row-scale pre-pass): its own roofline class (2516.6 / 3)
                 kernel = g.cfg == 0 ? "igemm_splith_128x128" : g.cfg == 7 ? "igemm_splith_64x128" : kernel;
+            else if (g.cfg == 0)
+            {
+                GemmArgs k{};
+                fill_gemm_geometry(k, g);
+                k.rowstat = g.rowstat >= 0 ? reinterpret_cast<float *>(1) : nullptr; // (only tested against null)
+                if (igemm_split_is_wide(g.cfg, k))
+                    kernel = "igemm_split_128x256";
+            }
         }
         flops = 2.0 * M * g.N * g.K;
         double in = (double)g.B * g.L1 * g.L0 * g.Cin, w = (double)g.N * g.K, out = 0;

@@ -522,6 +522,279 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
     igemm_epilogue<1, WMF, WNF, EPI, 256, 2>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
 }
 
+// ---- the linear-layer kernel on a 128 x 256 tile (round 6) -------------------------------------------------------------------
+//
+// igemm_split_lin_kernel spends, per 80 MFMAs of a wave, two 32-byte activation fetches and 88 VALU instructions of split work;
+// an ablation that fetched and split only every other K-tile (tools/micro/lin_variants.py linhalf: half of both per MFMA,
+// everything else as it is) took the 58 linear-layer ops of a 42-segment step from 24.7 to 21.6 ms. Twice the tile WIDTH is
+// the form of that which keeps two workgroups per CU: four waves stacked in M as before (32 rows each), 16 column fragments
+// per wave (128 accumulator registers), so a wave's activation planes meet twice as many weight columns. What pays for the
+// accumulators: the weight planes go global -> LDS directly (global_load_lds_dwordx4, the XOR swizzle applied to the SOURCE
+// octet: no staging registers, no ds_write), one K-tile ahead into the other image (2 x 32 KB per workgroup), and the weight
+// fragments are read two column fragments at a time into two alternating register sets.
+// Same operands in the same order per accumulator as every other exact-split tile: identical bits (the launcher takes this
+// kernel per LAUNCH, by the row count - batching and sharding still cannot change a bit). N a multiple of 256; row statistics
+// (linear2's LayerNorm partials) are written per 128 columns, as the 128-wide tiles write them.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs p)
+{
+    constexpr int KT = 32, WMF = 2, WNF = 16, BM = 128, BN = 256, NG = WNF / 2;
+    __shared__ u32x4 Bp[2][2][BN][4]; // [image][plane][column][octet slot]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    unsigned tileM, tileN;
+    if (!tile_of_block(p, tileM, tileN))
+        return;
+    const i64 m0 = (i64)tileM * BM;
+    const int n0 = (int)tileN * BN;
+    auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
+
+    unsigned aOff[WMF];
+    {
+        const i64 rowLen = (i64)p.L0 * p.Cin;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            const i64 m = min(m0 + wave * (WMF * 16) + i * 16 + l15, p.M - 1);
+            const int4 ri = row_info(p, m);
+            aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
+        }
+    }
+    // weight pieces: one wave instruction moves 1 KB = 16 columns x 4 octet slots of one plane; lane l lands at (column l / 4,
+    // slot l % 4) and therefore FETCHES octet (l % 4) ^ swz(column). Piece c = 8 wave + i: plane c / 16, columns 16 (c % 16) ...
+    // The per-lane part of the address is the same for all pieces (swz depends on (column / 4) % 4 = lane / 16 only); the piece's
+    // part is uniform.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned bVoff = ((unsigned)(lane >> 2) * (unsigned)p.Kp + 8u * (unsigned)((lane & 3) ^ swz(lane >> 2))) * 2u;
+    const char *bBase[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        const int c = wv * 8 + i, pl = c >> 4, cb = c & 15;
+        bBase[i] = reinterpret_cast<const char *>(pl ? p.Wb2 : p.Wb1) + (size_t)(n0 + 16 * cb) * (size_t)p.Kp * 2u;
+    }
+    auto dma_B = [&](int img) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const int c = wv * 8 + i, pl = c >> 4, cb = c & 15;
+            load_to_lds_b128(reinterpret_cast<const float *>(bBase[i] + bVoff), reinterpret_cast<float4 *>(&Bp[img][pl][16 * cb][0]));
+        }
+        bVoff += KT * 2;
+    };
+
+    f32x4 aRaw[2][WMF][2];
+    u32x4 aPl[2][WMF][3];
+    auto load_A = [&](auto setTag) {
+        constexpr int SET = decltype(setTag)::value;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+        {
+            const char *src = reinterpret_cast<const char *>(p.X) + aOff[i];
+            aRaw[SET][i][0] = *reinterpret_cast<const f32x4 *>(src);
+            aRaw[SET][i][1] = *reinterpret_cast<const f32x4 *>(src + 16);
+            aOff[i] += KT * 4;
+        }
+    };
+    auto split_block = [&](auto setTag, int i) {
+        constexpr int SET = decltype(setTag)::value;
+        const f32x4 lo = aRaw[SET][i][0], hi = aRaw[SET][i][1];
+        unsigned h1[4], h2[4], h3[4];
+        split3_pk(lo[0], lo[1], h1[0], h2[0], h3[0]);
+        split3_pk(lo[2], lo[3], h1[1], h2[1], h3[1]);
+        split3_pk(hi[0], hi[1], h1[2], h2[2], h3[2]);
+        split3_pk(hi[2], hi[3], h1[3], h2[3], h3[3]);
+        u32x4 q1{h1[0], h1[1], h1[2], h1[3]}, q2{h2[0], h2[1], h2[2], h2[3]}, q3{h3[0], h3[1], h3[2], h3[3]};
+        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3)); // (computed HERE, between the MFMA groups)
+        aPl[SET][i][0] = q1;
+        aPl[SET][i][1] = q2;
+        aPl[SET][i][2] = q3;
+    };
+
+    f32x4 acc[WMF][WNF];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+        for (int j = 0; j < WNF; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // pipeline: iteration kt multiplies tile kt (weight image PAR, activation planes aPl[PAR]); at its start it requests the
+    // activations of tile kt + 2 into register set PAR (free: split one iteration ago) and the weight pieces of tile kt + 1
+    // into the other image (free: every wave passed the barrier behind its last reads); between its MFMA groups it splits the
+    // activations of tile kt + 1. The activation loads are issued BEFORE the pieces, so waiting for them (vmcnt is in order)
+    // never waits for a piece; the pieces are waited for at the end, before the barrier that publishes them.
+    const std::integral_constant<int, 0> set0{};
+    const std::integral_constant<int, 1> set1{};
+    const int nk = p.Kp >> 5;
+    load_A(set0);
+    load_A(set1);
+    dma_B(0);
+    split_block(set0, 0);
+    split_block(set0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int fslot = kq ^ swz(l15);
+    auto iteration = [&](auto parTag) {
+        constexpr int PAR = decltype(parTag)::value;
+        const std::integral_constant<int, PAR ^ 1> other{};
+        load_A(parTag); // tile kt + 2 (beyond K: the row's next bytes, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        dma_B(PAR ^ 1); // tile kt + 1
+        u32x4 b1[2][2], b2[2][2];
+        auto read_group = [&](int g) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const int r = (2 * g + u) * 16 + l15;
+                b1[g & 1][u] = Bp[PAR][0][r][fslot];
+                b2[g & 1][u] = Bp[PAR][1][r][fslot];
+            }
+        };
+        auto term = [&](int g, u32x4(&b)[2], int plane) {
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    if constexpr (EPI == EPI_VT) // the transposed product (igemm_split_lin_kernel): activations as the matrix pipe's A operand
+                        acc[i][2 * g + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), __builtin_bit_cast(bf16x8, b[u]), acc[i][2 * g + u], 0, 0, 0);
+                    else
+                        acc[i][2 * g + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[u]), __builtin_bit_cast(bf16x8, aPl[PAR][i][plane]), acc[i][2 * g + u], 0, 0, 0);
+                }
+        };
+        read_group(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+        {
+            if (g + 1 < NG)
+                read_group(g + 1);
+            // smallest terms first: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
+            term(g, b1[g & 1], 2);
+            term(g, b2[g & 1], 1);
+            if (g == 2)
+                split_block(other, 0);
+            if (g == 5)
+                split_block(other, 1);
+            term(g, b2[g & 1], 0);
+            term(g, b1[g & 1], 1);
+            term(g, b1[g & 1], 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2)
+    {
+        iteration(set0);
+        if (kt + 1 < nk)
+            iteration(set1);
+    }
+
+    // ---- epilogue, four column fragments at a time (the generic epilogue would hold bias / scale / residual of all 16)
+    if constexpr (EPI == EPI_KPL || EPI == EPI_VT)
+    {
+        float2(*none)[1] = nullptr;
+        igemm_epilogue<1, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, none, m0, n0, tileN, wave, 0, BM);
+    }
+    else
+    {
+        static_assert(EPI == EPI_LINEAR || EPI == EPI_SCALE_RES, "plain linear layers");
+        const bool hasRes = EPI == EPI_SCALE_RES || p.res != nullptr;
+        // row statistics (linear2 feeds a LayerNorm): per 128 COLUMNS, as the 128-wide tiles write them - a run of four fragments
+        // summed per lane in fragment order, reduced over the row's four lanes, two runs added per entry (igemm_epilogue, SSEG = 2):
+        // this tile fills the entries 2 tileN and 2 tileN + 1 of its rows, same bits. The scratch aliases the weight images
+        // (every wave is past the last barrier of the K loop, no piece is in flight).
+        const bool wantStats = p.rowstat != nullptr;
+        float2(*rsum)[4] = reinterpret_cast<float2(*)[4]>(&Bp[0][0][0][0]);
+#pragma unroll
+        for (int jc = 0; jc < WNF; jc += 4)
+        {
+            float4 biasv[4], scalev[4], resv[WMF][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int n = n0 + (jc + j) * 16 + 4 * kq;
+                biasv[j] = *reinterpret_cast<const float4 *>(p.bias + n);
+                if (EPI == EPI_SCALE_RES)
+                    scalev[j] = *reinterpret_cast<const float4 *>(p.scale + n);
+#pragma unroll
+                for (int i = 0; i < WMF; ++i)
+                {
+                    const i64 m = m0 + wave * (WMF * 16) + i * 16 + l15;
+                    resv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (hasRes && m < p.M)
+                        resv[i][j] = *reinterpret_cast<const float4 *>(p.res + m * p.ldy + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+            {
+                const int rl = wave * (WMF * 16) + i * 16 + l15;
+                const i64 m = m0 + rl;
+                const bool rowOk = m < p.M;
+                float sm = 0.f, ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int n = n0 + (jc + j) * 16 + 4 * kq;
+                    const f32x4 a = acc[i][jc + j];
+                    if (rowOk)
+                    {
+                        float4 v = make_float4(a[0] + biasv[j].x, a[1] + biasv[j].y, a[2] + biasv[j].z, a[3] + biasv[j].w);
+                        if (EPI == EPI_LINEAR)
+                        {
+                            if (p.act)
+                                v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                            v.x += resv[i][j].x, v.y += resv[i][j].y, v.z += resv[i][j].z, v.w += resv[i][j].w;
+                        }
+                        else
+                            v = make_float4(resv[i][j].x + v.x * scalev[j].x, resv[i][j].y + v.y * scalev[j].y, resv[i][j].z + v.z * scalev[j].z,
+                                            resv[i][j].w + v.w * scalev[j].w);
+                        *reinterpret_cast<float4 *>(p.Y + m * p.ldy + n) = v;
+                        sm += (v.x + v.y) + (v.z + v.w);
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
+                }
+                if (wantStats)
+                {
+                    sm += __shfl_xor(sm, 16);
+                    ss += __shfl_xor(ss, 16);
+                    sm += __shfl_xor(sm, 32);
+                    ss += __shfl_xor(ss, 32);
+                    if (kq == 0)
+                    {
+                        rsum[rl][jc >> 2].x = sm;
+                        rsum[rl][jc >> 2].y = ss;
+                    }
+                }
+            }
+        }
+        if (wantStats)
+        {
+            __syncthreads();
+            for (int e = tid; e < 2 * BM; e += 256)
+            {
+                const int r = e >> 1, hb = e & 1;
+                const i64 m = m0 + r;
+                if (m < p.M)
+                {
+                    float sm = 0.f, ss = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w)
+                    {
+                        sm += rsum[r][2 * hb + w].x;
+                        ss += rsum[r][2 * hb + w].y;
+                    }
+                    float *dst = p.rowstat + (m * p.NB + 2 * tileN + hb) * 2;
+                    dst[0] = sm;
+                    dst[1] = ss;
+                }
+            }
+        }
+    }
+}
+
 // the kernels' activation split on an array (dmx_debug_split_activations: unit test of the split itself)
 __global__ void split3_debug_kernel(const float *x, i64 n, unsigned short *planes)
 {
@@ -601,6 +874,21 @@ void launch_split3h_debug(const float *d_x, i64 n, int sexp, unsigned short *d_p
 // arith 0: bf16 terms (every tile of the table below); arith 1: fp16 terms - only where igemm_split_lin_kernel applies
 // (linear-layer addressing, 128-wide tiles of at least 64 rows); returns -1 where it does not (the caller falls back to
 // arith 0). dry: decide only (needs the op's full geometry for arith 1).
+// The 128 x 256 linear-layer tile (igemm_split_linw_kernel) is taken per LAUNCH - it produces the bits of the 128-wide tiles -
+// where it pays: N a multiple of 256 and enough row tiles that the half as many, twice as large workgroups
+// still fill the 64 slots of an XCD at least `kWideMinRounds` times (the tile map deals row tiles to XCDs). DMX_SPLIT_LIN: 0 = the
+// staged 2 x 2-wave kernel, 2 = never the wide tile, 3 = the wide tile wherever it exists (bitwise A/B: tools/gpu_lin_ab.py).
+static constexpr double kWideMinRounds = 3.0;
+static bool wide_tile_pays(const GemmArgs &a, int mode)
+{
+    if (a.N % 256 != 0 || a.Np != a.N || a.Kp % 32 != 0 || mode == 2 || mode == 0 || (a.rowstat && a.NB != a.N / 128))
+        return false;
+    if (mode == 3)
+        return true;
+    const i64 tm = (a.M + 127) / 128;
+    return (double)(((tm + 7) / 8) * (a.N / 256)) / 64.0 >= kWideMinRounds;
+}
+
 template <int WM_, int WN_, int MF, int NF, int PRO, int EPI>
 static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool dry)
 {
@@ -627,8 +915,14 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
             {
                 if (dry)
                     return 0;
+                static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
                 if (arith == 1)
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
+                else if (MF == 4 && wide_tile_pays(a, mode == 0 ? 1 : mode))
+                {
+                    a.tilesN = (unsigned)(a.N / 256);
+                    hipLaunchKernelGGL((igemm_split_linw_kernel<EPI>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
+                }
                 else
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                 return 0;
@@ -654,7 +948,14 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
                         hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
                     return 0;
                 }
-                if (mode == 1)
+                if constexpr (MF == 4 && EPI != EPI_GLU)
+                    if (wide_tile_pays(a, mode))
+                    {
+                        a.tilesN = (unsigned)(a.N / 256);
+                        hipLaunchKernelGGL((igemm_split_linw_kernel<EPI>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
+                        return 0;
+                    }
+                if (mode != 0)
                 {
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
                     return 0;
@@ -671,6 +972,17 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
     if constexpr (EPI != EPI_KPL && EPI != EPI_VT)
         hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
     return 0;
+}
+
+// does launch_igemm_split run this op (tile cfg, geometry as api.cpp fill_gemm_geometry fills it) on the 128 x 256 linear-layer
+// kernel? (the per-op profile labels such launches igemm_split_128x256: dmx_debug_profile, bench.py)
+bool igemm_split_is_wide(int cfg, const GemmArgs &a)
+{
+    static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+    if (cfg != 0 || !(a.epi == EPI_LINEAR || a.epi == EPI_SCALE_RES || a.epi == EPI_KPL || a.epi == EPI_VT))
+        return false;
+    const bool lin = gemm_is_linear(a, a.pro, a.epi, 32) && ((i64)a.B * a.xBS + 64) * 4 < (1ll << 32);
+    return lin && wide_tile_pays(a, (a.epi == EPI_KPL || a.epi == EPI_VT) && mode == 0 ? 1 : mode);
 }
 
 // The MFMA-bound tile families only (plan.h kTileCfgs): 0 / 7 / 15 (2x2 waves, 4 column fragments), 9 / 16 (2 column

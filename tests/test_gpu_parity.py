@@ -1219,20 +1219,23 @@ def test_linear_layer_split_kernels_agree_bitwise(tmp_path):
     """The linear layers of a bf16x3 context run on igemm_split_lin_kernel (activation fragments loaded straight into
     registers, 4 x 1 waves of 8 column fragments) or, with DMX_SPLIT_LIN=0, on the staged 2 x 2-wave kernel: same tile map,
     same MFMA operand groups in the same order, row statistics summed as two runs of four fragments - so 4s and 6s tracks
-    are the same bits, with one segment per call (small tiles, staged kernel either way) and with six. The switch is read
-    once per process: two child processes (tools/gpu_lin_ab.py)."""
+    are the same bits, with one segment per call (small tiles, staged kernel either way) and with six. Round 6: the 128 x 256
+    tile (igemm_split_linw_kernel: weight planes by LDS-DMA, 16 column fragments per wave) replaces the 128 x 128 one per
+    LAUNCH where it pays - DMX_SPLIT_LIN=3 takes it wherever it exists (N % 256 == 0, no row statistics: linear1, q / k / qk /
+    v, out_proj, the 4s channel upsamplers), =2 never: the same bits again. The switch is read once per process: three child
+    processes (tools/gpu_lin_ab.py)."""
     import subprocess
     outs = []
-    for mode in ("0", "1"):
+    for mode in ("0", "2", "3"):
         out = str(tmp_path / f"lin_{mode}.npz")
         env = dict(os.environ, DMX_SPLIT_LIN=mode)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_lin_ab.py"), "run", out], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(out)
-    a, b = np.load(outs[0]), np.load(outs[1])
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 4
+    a, b, w = np.load(outs[0]), np.load(outs[1]), np.load(outs[2])
+    assert sorted(a.files) == sorted(b.files) == sorted(w.files) and len(a.files) == 4
     for k in a.files:
-        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]) and np.array_equal(a[k], w[k]), k
     for which in ("4s", "6s"):
         assert np.array_equal(b[f"{which}_track_b1"], b[f"{which}_track_b6"]), which
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the linear-layer split kernels (DMX_SPLIT_LIN = 0 staged / 1 fragments in registers / 2 experiment): every mode
-must produce the same bits. `run <out.npz>` writes the outputs of this process's mode; `cmp a.npz b.npz` compares."""
+"""A/B of the linear-layer split kernels (DMX_SPLIT_LIN = 0 staged / 1 default: fragments in registers, 128 x 256 tile where
+it pays / 2 never the 128 x 256 tile / 3 the 128 x 256 tile wherever it exists): every mode must produce the same bits. `run <out.npz>` writes the outputs of this process's mode; `cmp a.npz b.npz` compares."""
 import os
 import sys
 

@@ -24,6 +24,10 @@ def kernel_class(name: str) -> str:
     if m:
         mf, nf = (int(x) for x in m.groups())
         return f"igemm_split_{4 * mf * 16}x{nf * 16}"
+    if "igemm_split_linw_kernel" in name:  # the 128 x 256 linear-layer tile
+        return "igemm_split_128x256"
+    if "dconv_row_kernel" in name:
+        return "dconv_row"
     if "igemm_lin256_kernel" in name:
         return "igemm_lin256x128"
     for key, cls in (("lstm_kernel", "lstm"), ("local_attn_kernel", "local_attn"), ("group_stats", "group_stats"), ("gn_act_kernel", "gn_act"),
