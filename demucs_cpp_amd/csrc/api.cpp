@@ -1465,13 +1465,14 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
                 kernel = splitNames[g.cfg];
             if (g.split == 2) // fp16 terms (+ the row-scale pre-pass): its own roofline class (2516.6 / 3)
                 kernel = g.cfg == 0 ? "igemm_splith_128x128" : g.cfg == 7 ? "igemm_splith_64x128" : kernel;
-            else if (g.cfg == 0)
+            else if (g.cfg == 0 || g.cfg == 2)
             {
                 GemmArgs k{};
                 fill_gemm_geometry(k, g);
                 k.rowstat = g.rowstat >= 0 ? reinterpret_cast<float *>(1) : nullptr; // (only tested against null)
-                if (igemm_split_is_wide(g.cfg, k))
-                    kernel = "igemm_split_128x256";
+                const int wide = igemm_split_is_wide(g.cfg, k);
+                if (wide) // (96: the same tile as cfg 2 with the activation fragments loaded straight into registers)
+                    kernel = wide == 256 ? "igemm_split_128x256" : wide == 192 ? "igemm_split_128x192" : "igemm_split_128x96d";
             }
         }
         flops = 2.0 * M * g.N * g.K;

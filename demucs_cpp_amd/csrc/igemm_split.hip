@@ -535,10 +535,21 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 // Same operands in the same order per accumulator as every other exact-split tile: identical bits (the launcher takes this
 // kernel per LAUNCH, by the row count - batching and sharding still cannot change a bit). N a multiple of 256; row statistics
 // (linear2's LayerNorm partials) are written per 128 columns, as the 128-wide tiles write them.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs p)
+//
+// Generalised in the same round (WNF, GEN): WNF = 12 is the 128 x 192 tile for N = 192 / 384 layers; GEN = true gives the
+// activation fragments CONV addressing - a row's K axis is S1 runs of seg0 contiguous floats with whole-tap padding
+// (igemm_common.h StageWalk): with Cin a multiple of 8 a lane's 8 consecutive k never leave one tap, so the fragment is still
+// two 16-byte loads, from (row base) + (run offset) where the row's tap bit is set and from the zero page where it is not. The
+// strided convs (k8 s4), the 3x3 / k3 rewrites, the transposed convs (K = 2 Cin) and the 1x1 rewrites of the C = 96 / 192 /
+// 384 levels were two (N = 192) to six (N = 768) 96- or 128-wide tiles that each fetched AND split the same activation rows;
+// here a row is fetched and split once per 192 / 256 columns and never passes through LDS. K-tile order, chunk -> (run, tap)
+// walk and term order are those of igemm_split_kernel: the same bits (per-launch choice, tools/gpu_lin_ab.py).
+template <int WNF, int EPI, bool GEN>
+__global__ __launch_bounds__(256, WNF == 6 ? 3 : 2) void igemm_split_linw_kernel(const GemmArgs p)
 {
-    constexpr int KT = 32, WMF = 2, WNF = 16, BM = 128, BN = 256, NG = WNF / 2;
+    constexpr int KT = 32, WMF = 2, BM = 128, BN = 16 * WNF, NG = WNF / 2;
+    constexpr int PW = WNF / 2; // weight pieces (1 KB = 16 columns of one plane) per wave and K-tile
+    static_assert(WNF == 16 || WNF == 12 || WNF == 6, "128 x 256 / 128 x 192 / 128 x 96 (N = 96 layers: three workgroups per CU)");
     __shared__ u32x4 Bp[2][2][BN][4]; // [image][plane][column][octet slot]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -550,7 +561,16 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
     const int n0 = (int)tileN * BN;
     auto rowinfo_of = [&](int r) -> int4 { return row_info(p, m0 + r); };
 
+    // activation rows of this lane: block i = rows wave * 32 + 16 i + l15, k-octet kq (rows beyond M read the last valid row;
+    // their accumulators are never stored). Linear addressing: one 32-bit byte offset per block that advances by a K-tile.
+    // GEN: the row's base for (tap 0, k 0) - it may lie before the tensor where padding starts a row - and one validity bit per
+    // tap (StageWalk's rule: padding starts and ends at whole taps); the lane walks its octet's (run s1, offset in the run, tap)
+    // without divisions, the same for both blocks.
     unsigned aOff[WMF];
+    const float *aRow[WMF];
+    unsigned aMask[WMF];
+    int gS1 = 0, gOffb = kq * 8, gTapC = 0, gTapOff = kq * 8;
+    const int rowLenI = p.L0 * p.Cin;
     {
         const i64 rowLen = (i64)p.L0 * p.Cin;
 #pragma unroll
@@ -558,27 +578,62 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
         {
             const i64 m = min(m0 + wave * (WMF * 16) + i * 16 + l15, p.M - 1);
             const int4 ri = row_info(p, m);
-            aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
+            aOff[i] = 0, aRow[i] = p.X, aMask[i] = 0;
+            if constexpr (GEN)
+            {
+                const int taps0 = p.seg0 / p.Cin;
+                const int in1_0 = ri.y * p.stride1 - p.pad1;
+                const int e0 = (ri.z * p.stride0 - p.pad0) * p.Cin;
+                aRow[i] = p.X + (i64)ri.x * p.xBS + (i64)in1_0 * rowLen + e0;
+                unsigned m0bits = 0; // taps along axis 0 whose chunk lies inside the row
+                for (int t0 = 0; t0 < taps0; ++t0)
+                {
+                    const int e = e0 + t0 * p.Cin;
+                    m0bits |= (e >= 0 && e < rowLenI ? 1u : 0u) << t0;
+                }
+                for (int s = 0; s < p.S1; ++s)
+                {
+                    const int in1 = in1_0 + s * p.dil1;
+                    if (in1 >= 0 && in1 < p.L1)
+                        aMask[i] |= m0bits << (s * taps0);
+                }
+            }
+            else
+                aOff[i] = (unsigned)(((i64)ri.x * p.xBS + (i64)ri.y * rowLen + (i64)ri.z * p.stride0 * p.Cin) * 4 + kq * 32);
+        }
+        if constexpr (GEN)
+        {
+            if (p.S1 > 1)
+                while (gOffb >= p.seg0)
+                {
+                    gOffb -= p.seg0;
+                    ++gS1;
+                }
+            while (gTapOff >= p.Cin)
+            {
+                gTapOff -= p.Cin;
+                ++gTapC;
+            }
         }
     }
     // weight pieces: one wave instruction moves 1 KB = 16 columns x 4 octet slots of one plane; lane l lands at (column l / 4,
-    // slot l % 4) and therefore FETCHES octet (l % 4) ^ swz(column). Piece c = 8 wave + i: plane c / 16, columns 16 (c % 16) ...
+    // slot l % 4) and therefore FETCHES octet (l % 4) ^ swz(column). Piece c = PW wave + i: plane c / WNF, columns 16 (c % WNF) ...
     // The per-lane part of the address is the same for all pieces (swz depends on (column / 4) % 4 = lane / 16 only); the piece's
     // part is uniform.
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     unsigned bVoff = ((unsigned)(lane >> 2) * (unsigned)p.Kp + 8u * (unsigned)((lane & 3) ^ swz(lane >> 2))) * 2u;
-    const char *bBase[8];
+    const char *bBase[PW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < PW; ++i)
     {
-        const int c = wv * 8 + i, pl = c >> 4, cb = c & 15;
+        const int c = wv * PW + i, pl = c / WNF, cb = c % WNF;
         bBase[i] = reinterpret_cast<const char *>(pl ? p.Wb2 : p.Wb1) + (size_t)(n0 + 16 * cb) * (size_t)p.Kp * 2u;
     }
     auto dma_B = [&](int img) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < PW; ++i)
         {
-            const int c = wv * 8 + i, pl = c >> 4, cb = c & 15;
+            const int c = wv * PW + i, pl = c / WNF, cb = c % WNF;
             load_to_lds_b128(reinterpret_cast<const float *>(bBase[i] + bVoff), reinterpret_cast<float4 *>(&Bp[img][pl][16 * cb][0]));
         }
         bVoff += KT * 2;
@@ -588,6 +643,31 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
     u32x4 aPl[2][WMF][3];
     auto load_A = [&](auto setTag) {
         constexpr int SET = decltype(setTag)::value;
+        if constexpr (GEN)
+        {
+            const unsigned tapBit = gTapC < 32 ? 1u << gTapC : 0u; // taps beyond K have no bit in any row mask
+            const int segOff = gS1 * p.dil1 * rowLenI + gOffb;     // fits int32 for every layer of the model
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+            {
+                const float *src = (aMask[i] & tapBit) ? aRow[i] + segOff : p.zero; // (the zero page holds 64 floats)
+                aRaw[SET][i][0] = *reinterpret_cast<const f32x4 *>(src);
+                aRaw[SET][i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            }
+            gOffb += KT;
+            if (p.S1 > 1 && gOffb >= p.seg0) // (seg0 >= 32: the launcher checks)
+            {
+                gOffb -= p.seg0;
+                ++gS1;
+            }
+            gTapOff += KT;
+            while (gTapOff >= p.Cin)
+            {
+                gTapOff -= p.Cin;
+                ++gTapC;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < WMF; ++i)
         {
@@ -626,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
     // never waits for a piece; the pieces are waited for at the end, before the barrier that publishes them.
     const std::integral_constant<int, 0> set0{};
     const std::integral_constant<int, 1> set1{};
-    const int nk = p.Kp >> 5;
+    const int nk = (p.Kp + 31) >> 5; // (GEN: Kp may be an odd multiple of 16 - the last half tile meets zero-page activations)
     load_A(set0);
     load_A(set1);
     dma_B(0);
@@ -672,9 +752,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
             // smallest terms first: a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
             term(g, b1[g & 1], 2);
             term(g, b2[g & 1], 1);
-            if (g == 2)
+            if (g == (WNF == 16 ? 2 : WNF == 12 ? 1 : 0))
                 split_block(other, 0);
-            if (g == 5)
+            if (g == (WNF == 16 ? 5 : WNF == 12 ? 4 : 2))
                 split_block(other, 1);
             term(g, b2[g & 1], 0);
             term(g, b1[g & 1], 1);
@@ -696,6 +776,24 @@ __global__ __launch_bounds__(256, 2) void igemm_split_linw_kernel(const GemmArgs
     {
         float2(*none)[1] = nullptr;
         igemm_epilogue<1, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, none, m0, n0, tileN, wave, 0, BM);
+    }
+    else if constexpr (GEN || WNF != 16)
+    {
+        // the shared epilogue (igemm_common.h), four column fragments at a time: GLU pairs are adjacent fragments, the
+        // transposed-conv scatter and the linear epilogue are per fragment. No row statistics on this path (the launcher checks).
+        float2(*none)[1] = nullptr;
+        constexpr int JC = WNF % 4 == 0 ? 4 : 6;
+#pragma unroll
+        for (int jc = 0; jc < WNF; jc += JC)
+        {
+            f32x4 part[WMF][JC];
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < JC; ++j)
+                    part[i][j] = acc[i][jc + j];
+            igemm_epilogue<1, WMF, JC, EPI, 256>(p, part, rowinfo_of, none, m0, n0 + 16 * jc, tileN, wave, 0, BM);
+        }
     }
     else
     {
@@ -889,6 +987,39 @@ static bool wide_tile_pays(const GemmArgs &a, int mode)
     return (double)(((tm + 7) / 8) * (a.N / 256)) / 64.0 >= kWideMinRounds;
 }
 
+// The conv-addressed wide tiles (igemm_split_linw_kernel<WNF, EPI, true>): column fragments per wave (16 = 128 x 256, 12 =
+// 128 x 192) this launch takes, or 0. Ops of the full-height 128 x 128 / 128 x 96 tiles without prologue and row statistics whose
+// A rows are runs of whole 8-float pieces (Cin a multiple of 8) and whose width is whole wide tiles; per LAUNCH, by the same
+// occupancy rule as wide_tile_pays (the results are the bits of the narrow tiles). mode = DMX_SPLIT_LIN (0 / 2: never, 3: always).
+static int wide_conv_width(const GemmArgs &a, int pro, int epi, int mode)
+{
+    if (mode == 0 || mode == 2 || pro != PRO_NONE || !(epi == EPI_LINEAR || epi == EPI_GLU || epi == EPI_TRCONV) || a.rowstat)
+        return 0;
+    const int wnf = a.N % 256 == 0 ? 16 : a.N % 192 == 0 ? 12 : a.N == 96 ? 6 : 0;
+    if (!wnf || a.Np != a.N || a.Kp % 16 != 0 || a.Cin % 8 != 0 || a.seg0 % a.Cin != 0 || a.seg0 < 32 || a.S1 * (a.seg0 / a.Cin) > 32 ||
+        (i64)a.S1 * a.dil1 * a.L0 * a.Cin + a.seg0 >= (1ll << 31) || (epi == EPI_TRCONV && a.Cout % 4 != 0))
+        return 0;
+    if (mode == 3)
+        return wnf;
+    if (mode == 4 && wnf == 6) // (A/B switch: the 96-wide layers stay on the staged tile)
+        return 0;
+    const i64 tm = (a.M + 127) / 128;
+    return (double)(((tm + 7) / 8) * (a.N / (16 * wnf))) / 64.0 >= kWideMinRounds ? wnf : 0;
+}
+template <int EPI>
+static void launch_wide_conv(GemmArgs a, int wnf, hipStream_t s)
+{
+    a.tilesM = (unsigned)((a.M + 127) / 128);
+    a.tilesN = (unsigned)(a.N / (16 * wnf));
+    const dim3 grid(8u * ((a.tilesM + 7u) / 8u) * a.tilesN);
+    if (wnf == 16)
+        hipLaunchKernelGGL((igemm_split_linw_kernel<16, EPI, true>), grid, dim3(256), 0, s, a);
+    else if (wnf == 12)
+        hipLaunchKernelGGL((igemm_split_linw_kernel<12, EPI, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((igemm_split_linw_kernel<6, EPI, true>), grid, dim3(256), 0, s, a);
+}
+
 template <int WM_, int WN_, int MF, int NF, int PRO, int EPI>
 static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool dry)
 {
@@ -921,7 +1052,7 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
                 else if (MF == 4 && wide_tile_pays(a, mode == 0 ? 1 : mode))
                 {
                     a.tilesN = (unsigned)(a.N / 256);
-                    hipLaunchKernelGGL((igemm_split_linw_kernel<EPI>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL((igemm_split_linw_kernel<16, EPI, false>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
                 }
                 else
                     hipLaunchKernelGGL((igemm_split_lin_kernel<MF / 2, 8, EPI>), dim3(blocks), dim3(256), 0, s, a);
@@ -932,6 +1063,18 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
     }
     else if constexpr (PRO == PRO_NONE && (EPI == EPI_LINEAR || EPI == EPI_SCALE_RES || EPI == EPI_GLU))
     {
+        // plain linear layers of a width the 128 x 256 linear tile takes go there (below); every other full-height op of these
+        // epilogues - strided convs, 3x3 / k3 / 1x1 rewrites - to the conv-addressed wide tiles where they exist and pay
+        if constexpr (EPI != EPI_SCALE_RES && ((WM_ == 2 && WN_ == 2 && MF == 4 && NF == 4) || (WM_ == 4 && WN_ == 1 && MF == 2 && NF == 6)))
+            if (arith == 0 && !(lin && EPI == EPI_LINEAR && a.N % 256 == 0))
+            {
+                static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+                if (const int wnf = wide_conv_width(a, PRO, EPI, mode))
+                {
+                    launch_wide_conv<EPI>(a, wnf, s);
+                    return 0;
+                }
+            }
         if (lin)
         {
             // 128-wide tiles of at least 64 rows: activation fragments straight into registers (igemm_split_lin_kernel);
@@ -952,7 +1095,7 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
                     if (wide_tile_pays(a, mode))
                     {
                         a.tilesN = (unsigned)(a.N / 256);
-                        hipLaunchKernelGGL((igemm_split_linw_kernel<EPI>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
+                        hipLaunchKernelGGL((igemm_split_linw_kernel<16, EPI, false>), dim3(8u * ((a.tilesM + 7u) / 8u) * a.tilesN), dim3(256), 0, s, a);
                         return 0;
                     }
                 if (mode != 0)
@@ -969,20 +1112,35 @@ static int launch_split_one(const GemmArgs &a0, hipStream_t s, int arith, bool d
     }
     if (arith == 1)
         return -1;
+    if constexpr (PRO == PRO_NONE && EPI == EPI_TRCONV && ((WM_ == 2 && WN_ == 2 && MF == 4 && NF == 4) || (WM_ == 4 && WN_ == 1 && MF == 2 && NF == 6)))
+    {
+        static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
+        if (const int wnf = wide_conv_width(a, PRO, EPI, mode))
+        {
+            launch_wide_conv<EPI>(a, wnf, s);
+            return 0;
+        }
+    }
     if constexpr (EPI != EPI_KPL && EPI != EPI_VT)
         hipLaunchKernelGGL((igemm_split_kernel<WM_, WN_, MF, NF, PRO, EPI, false>), dim3(blocks), dim3(256), 0, s, a);
     return 0;
 }
 
-// does launch_igemm_split run this op (tile cfg, geometry as api.cpp fill_gemm_geometry fills it) on the 128 x 256 linear-layer
-// kernel? (the per-op profile labels such launches igemm_split_128x256: dmx_debug_profile, bench.py)
-bool igemm_split_is_wide(int cfg, const GemmArgs &a)
+// does launch_igemm_split run this op (tile cfg, geometry as api.cpp fill_gemm_geometry fills it) on a wide tile of
+// igemm_split_linw_kernel? 0, or the tile's width 256 / 192 (the per-op profile labels such launches igemm_split_128x256 /
+// igemm_split_128x192: dmx_debug_profile, bench.py)
+int igemm_split_is_wide(int cfg, const GemmArgs &a)
 {
     static const int mode = [] { const char *e = getenv("DMX_SPLIT_LIN"); return e ? atoi(e) : 1; }();
-    if (cfg != 0 || !(a.epi == EPI_LINEAR || a.epi == EPI_SCALE_RES || a.epi == EPI_KPL || a.epi == EPI_VT))
-        return false;
+    if (cfg != 0 && cfg != 2)
+        return 0;
     const bool lin = gemm_is_linear(a, a.pro, a.epi, 32) && ((i64)a.B * a.xBS + 64) * 4 < (1ll << 32);
-    return lin && wide_tile_pays(a, (a.epi == EPI_KPL || a.epi == EPI_VT) && mode == 0 ? 1 : mode);
+    if (cfg == 0 && lin && (a.epi == EPI_LINEAR || a.epi == EPI_SCALE_RES || a.epi == EPI_KPL || a.epi == EPI_VT) &&
+        wide_tile_pays(a, (a.epi == EPI_KPL || a.epi == EPI_VT) && mode == 0 ? 1 : mode))
+        return 256;
+    if (lin && a.epi == EPI_LINEAR && a.N % 256 == 0) // (launch_split_one: these stay with the linear-layer kernels)
+        return 0;
+    return 16 * wide_conv_width(a, a.pro, a.epi, mode);
 }
 
 // The MFMA-bound tile families only (plan.h kTileCfgs): 0 / 7 / 15 (2x2 waves, 4 column fragments), 9 / 16 (2 column

@@ -97,8 +97,9 @@ int launch_igemm_lin256(const GemmArgs &a, hipStream_t s, bool dry = false);
 // arith 0: bf16 terms (DMX_GEMM_BF16X3); 1: fp16 terms (DMX_GEMM_FP16X3: Wb1 = the fp16 plane, rowScale set) - exists for the
 // linear-layer kernel only, returns -1 elsewhere; a dry call with arith 1 needs the op's whole geometry in `a`
 int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry = false, int arith = 0);
-// true: that launch takes the 128 x 256 linear-layer tile (igemm_split_linw_kernel), decided per launch; same bits either way
-bool igemm_split_is_wide(int cfg, const GemmArgs &a);
+// 256 / 192: that launch takes a wide tile of igemm_split_linw_kernel (128 x 256 / 128 x 192), decided per launch; 0: it does not.
+// Same bits either way
+int igemm_split_is_wide(int cfg, const GemmArgs &a);
 // per-row scales of a linear layer's A operand (rows of K contiguous floats, the addressing of `a`): out[m] = rowscale_of(max |a|)
 void launch_rowscale(const GemmArgs &a, float *out, hipStream_t s);
 // the fp16 three-term split applied to an array under ONE scale 2^sexp: planes [3][n] fp16 bit patterns (unit test of the split)

@@ -24,8 +24,9 @@ def kernel_class(name: str) -> str:
     if m:
         mf, nf = (int(x) for x in m.groups())
         return f"igemm_split_{4 * mf * 16}x{nf * 16}"
-    if "igemm_split_linw_kernel" in name:  # the 128 x 256 linear-layer tile
-        return "igemm_split_128x256"
+    m = re.search(r"igemm_split_linw_kernel<(\d+)", name)  # the wide tiles (128 x 256 / 192; 6 fragments: 128 x 96, direct fragments)
+    if m:
+        return {16: "igemm_split_128x256", 12: "igemm_split_128x192"}.get(int(m.group(1)), "igemm_split_128x96d")
     if "dconv_row_kernel" in name:
         return "dconv_row"
     if "igemm_lin256_kernel" in name:
