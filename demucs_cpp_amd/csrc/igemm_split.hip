@@ -976,7 +976,7 @@ void launch_split3h_debug(const float *d_x, i64 n, int sexp, unsigned short *d_p
 // where it pays: N a multiple of 256 and enough row tiles that the half as many, twice as large workgroups
 // still fill the 64 slots of an XCD at least `kWideMinRounds` times (the tile map deals row tiles to XCDs). DMX_SPLIT_LIN: 0 = the
 // staged 2 x 2-wave kernel, 2 = never the wide tile, 3 = the wide tile wherever it exists (bitwise A/B: tools/gpu_lin_ab.py).
-static constexpr double kWideMinRounds = 3.0;
+static constexpr double kWideMinRounds = 2.5; // (2.62 rounds: linear1 1 - 3 % faster on the wide tile; 1.75: level)
 static bool wide_tile_pays(const GemmArgs &a, int mode)
 {
     if (a.N % 256 != 0 || a.Np != a.N || a.Kp % 32 != 0 || mode == 2 || mode == 0 || (a.rowstat && a.NB != a.N / 128))
@@ -1003,8 +1003,14 @@ static int wide_conv_width(const GemmArgs &a, int pro, int epi, int mode)
         return wnf;
     if (mode == 4 && wnf == 6) // (A/B switch: the 96-wide layers stay on the staged tile)
         return 0;
+    // Measured at 1 - 42 segments per call against the narrow tile the plan chose (profiles/r06_experiments/wide_tile_rounds.txt):
+    // the 96-wide form has the narrow tile's workgroup count and wins everywhere (13 - 24 %); an N = 192 layer replaces TWO 96-wide
+    // tiles and is never slower from 0.66 rounds of an XCD's 64 slots on; the others pay from about one round (N = 768 at 0.98
+    // rounds: 5 - 14 % faster; N = 384 / 512 at 0.66 rounds: 10 - 25 % slower)
+    if (wnf == 6)
+        return wnf;
     const i64 tm = (a.M + 127) / 128;
-    return (double)(((tm + 7) / 8) * (a.N / (16 * wnf))) / 64.0 >= kWideMinRounds ? wnf : 0;
+    return (double)(((tm + 7) / 8) * (a.N / (16 * wnf))) / 64.0 >= (a.N == 192 ? 0.6 : 0.9) ? wnf : 0;
 }
 template <int EPI>
 static void launch_wide_conv(GemmArgs a, int wnf, hipStream_t s)
