@@ -258,7 +258,11 @@ struct Builder
         // the DConv k3 op is a copy of k2 with another epilogue: both are in the direct table
         // (the direct kernels carry no residual operand for the LINEAR / TRCONV epilogues)
         const bool resOk = !((g.epi == EPI_LINEAR || g.epi == EPI_TRCONV) && g.res >= 0);
-        if (resOk && (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
+        // the level-0 1x1 rewrites (48 -> 96 + GLU) of an exact-split context run on the 128 x 96 direct-fragment split tile
+        // (igemm_split.hip, round 6): 0.900 -> 0.815 / 0.435 -> 0.386 ms at 42 segments against the fp32 direct kernel, which
+        // sits on the fp32 matrix pipe's ridge; an fp32 context keeps the direct kernel (its tiled fp32 form is 20 % slower)
+        const bool rewrite0Split = opts.gemm != GEMM_F32 && g.pro == PRO_NONE && g.epi == EPI_GLU && g.S1 == 1 && g.seg0 == 48 && g.N == 96;
+        if (resOk && !rewrite0Split && (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
                       (g.epi == EPI_STATS_ONLY && direct_available(g.N, g.S1, g.seg0, g.pro, EPI_GN_GLU_SCALE_RES))))
             g.cfg = kDirectCfg;
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
