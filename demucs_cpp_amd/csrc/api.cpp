@@ -1457,9 +1457,9 @@ static void op_work(const Op &op, const char *&kernel, double &flops, double &by
         kernel = cfgNames[g.cfg];
         if (g.split) // exact bf16 operand-split kernel of the same tile (igemm_split.hip): its own roofline class
         {
-            static const char *splitNames[kNumTileCfgs] = {"igemm_split_128x128", nullptr, "igemm_split_128x96", "igemm_split_128x48", nullptr, "igemm_split_128x32d", nullptr,
+            static const char *splitNames[kNumTileCfgs] = {"igemm_split_128x128", nullptr, "igemm_split_128x96", "igemm_split_128x48", nullptr, "igemm_split_128x32d", "igemm_split_128x64d",
                                                             "igemm_split_64x128", nullptr, "igemm_split_64x64", "igemm_split_64x96", "igemm_split_64x48",
-                                                            "igemm_split_128x32d", nullptr, nullptr, "igemm_split_32x128", "igemm_split_32x64", nullptr, nullptr,
+                                                            "igemm_split_128x32d", "igemm_split_128x64d", nullptr, "igemm_split_32x128", "igemm_split_32x64", nullptr, nullptr,
                                                             nullptr, nullptr};
             if (splitNames[g.cfg])
                 kernel = splitNames[g.cfg];

@@ -545,12 +545,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 // here a row is fetched and split once per 192 / 256 columns and never passes through LDS. K-tile order, chunk -> (run, tap)
 // walk and term order are those of igemm_split_kernel: the same bits (per-launch choice, tools/gpu_lin_ab.py).
 template <int WNF, int EPI, bool GEN>
-__global__ __launch_bounds__(256, WNF == 2 ? 4 : WNF == 6 ? 3 : 2) void igemm_split_linw_kernel(const GemmArgs p)
+__global__ __launch_bounds__(256, WNF == 2 ? 4 : WNF <= 6 ? 3 : 2) void igemm_split_linw_kernel(const GemmArgs p)
 {
     constexpr int KT = 32, WMF = 2, BM = 128, BN = 16 * WNF, NG = WNF / 2;
     constexpr int PW = WNF / 2; // weight pieces (1 KB = 16 columns of one plane) per wave and K-tile
-    static_assert(WNF == 16 || WNF == 12 || WNF == 6 || WNF == 2,
-                  "128 x 256 / 128 x 192 / 128 x 96 (N = 96 layers: three workgroups per CU) / 128 x 32 (the C = 192 DConv K1, N = 24: four)");
+    static_assert(WNF == 16 || WNF == 12 || WNF == 6 || WNF == 4 || WNF == 2,
+                  "128 x 256 / 128 x 192 / 128 x 96 (N = 96 layers: three workgroups per CU) / 128 x 64 (the last transposed conv of the "
+                  "frequency branch, N = 64: three) / 128 x 32 (the C = 192 DConv K1, N = 24: four)");
     __shared__ u32x4 Bp[2][2][BN][4]; // [image][plane][column][octet slot]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256, WNF == 2 ? 4 : WNF == 6 ? 3 : 2) void igemm_sp
             term(g, b2[g & 1], 1);
             if (g == (WNF == 16 ? 2 : WNF == 12 ? 1 : 0))
                 split_block(other, 0);
-            if (g == (WNF == 16 ? 5 : WNF == 12 ? 4 : WNF == 6 ? 2 : 0))
+            if (g == (WNF == 16 ? 5 : WNF == 12 ? 4 : WNF == 6 ? 2 : WNF == 4 ? 1 : 0))
                 split_block(other, 1);
             term(g, b2[g & 1], 0);
             term(g, b1[g & 1], 1);
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256, WNF == 2 ? 4 : WNF == 6 ? 3 : 2) void igemm_sp
         // one column block with row statistics (the DConv K1: its GroupNorm partials per row, plan.h rowstat): the shared epilogue
         // whole; the scratch aliases the weight images (every wave is past the K loop's last barrier, no piece is in flight)
         float2(*rsum)[1] = reinterpret_cast<float2(*)[1]>(&Bp[0][0][0][0]);
-        igemm_epilogue<1, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM);
+        igemm_epilogue<1, WMF, WNF, EPI, 256>(p, acc, rowinfo_of, rsum, m0, n0, tileN, wave, 0, BM); // (EPI_TRCONV: no statistics)
     }
     else if constexpr (GEN || WNF != 16)
     {
@@ -1034,18 +1035,23 @@ static void launch_wide_conv(GemmArgs a, int wnf, hipStream_t s)
         hipLaunchKernelGGL((igemm_split_linw_kernel<6, EPI, true>), grid, dim3(256), 0, s, a);
 }
 
-// The 32-wide layers (N <= 32: the DConv K1 of the C = 192 levels, Conv1d(192 -> 24, k3): K = 576) in exact-split arithmetic: the
-// 128 x 32 form of the direct-fragment kernel, one column block, row statistics. Their fp32 tile (igemm_128x32) fetched every
-// input row three times through LDS staging at 2.7x the algorithmic HBM traffic; here the 88 split operations per 20 MFMAs that
-// kept the staged split tile level with fp32 (round 4) are spread over three workgroups per CU with nothing else to do.
-// Taken at every batch size (tile cfg 5 and its half-height sibling 12 alike: one arithmetic per op); -1 where the conditions
-// fail - the op keeps its fp32 kernel. dry: decided from the op's whole geometry (api.cpp split_ok fills it).
-static int launch_split_narrow(const GemmArgs &a0, hipStream_t s, int arith, bool dry)
+// The narrow layers in exact-split arithmetic on the direct-fragment kernel, taken at EVERY batch size (full-height tile cfg and
+// its half-height sibling alike: one arithmetic per op); -1 where the conditions fail - the op keeps its fp32 kernel. dry: decided
+// from the op's whole geometry (api.cpp split_ok fills it).
+//   cfg 5 / 12, N <= 32 (128 x 32, four workgroups per CU): the DConv K1 of the C = 192 levels (Conv1d(192 -> 24, k3): K = 576; row
+//     statistics) - its fp32 tile (igemm_128x32) fetched every input row three times through LDS staging at 2.7x the algorithmic
+//     HBM traffic; here the 88 split operations per 20 MFMAs that kept the staged split tile level with fp32 (round 4) are spread
+//     over four workgroups per CU with nothing else to do (1.10 -> 1.03 ms per 42-segment step: the op is bound by its fragment loads);
+//   cfg 6 / 13, N = 64 (128 x 64, three workgroups per CU): the frequency branch's last transposed conv of a 4-source model
+//     (48 -> 4 x 16, K = 96), which sat on the fp32 matrix pipe at 60 % of its peak in the direct kernel (plan.cpp finish).
+static int launch_split_narrow(int cfg, const GemmArgs &a0, hipStream_t s, int arith, bool dry)
 {
     const GemmArgs &a = a0;
-    if (arith != 0 || a.pro != PRO_NONE || a.epi != EPI_LINEAR || a.res || a.N > 32 || a.Np != 32 || a.Kp % 16 != 0 || a.Cin % 8 != 0 || a.Cin <= 0 ||
-        a.seg0 % a.Cin != 0 || a.seg0 < 32 || a.S1 * (a.seg0 / a.Cin) > 32 || (i64)a.S1 * a.dil1 * a.L0 * a.Cin + a.seg0 >= (1ll << 31) ||
-        (a.NB != 1))
+    const int np = (cfg == 5 || cfg == 12) ? 32 : 64;
+    if (arith != 0 || a.pro != PRO_NONE || !(a.epi == EPI_LINEAR || (a.epi == EPI_TRCONV && np == 64)) || (a.epi == EPI_LINEAR && a.res) || a.N > np || a.Np != np ||
+        a.Kp % 16 != 0 || a.Cin % 8 != 0 || a.Cin <= 0 || a.seg0 % a.Cin != 0 || a.seg0 < 32 || a.S1 * (a.seg0 / a.Cin) > 32 ||
+        (i64)a.S1 * a.dil1 * a.L0 * a.Cin + a.seg0 >= (1ll << 31) || a.NB != 1 || (a.epi == EPI_TRCONV && (a.rowstat || a.Cout % 4 != 0)) ||
+        (np == 64 && a.rowstat))
         return -1;
     if (dry)
         return 0;
@@ -1054,7 +1060,13 @@ static int launch_split_narrow(const GemmArgs &a0, hipStream_t s, int arith, boo
     k.tilesN = 1;
     k.xcdMap = 1;
     k.dP0 = make_fastdiv((unsigned)k.P0), k.dP1 = make_fastdiv((unsigned)k.P1);
-    hipLaunchKernelGGL((igemm_split_linw_kernel<2, EPI_LINEAR, true>), dim3(8u * ((k.tilesM + 7u) / 8u)), dim3(256), 0, s, k);
+    const dim3 grid(8u * ((k.tilesM + 7u) / 8u));
+    if (np == 32)
+        hipLaunchKernelGGL((igemm_split_linw_kernel<2, EPI_LINEAR, true>), grid, dim3(256), 0, s, k);
+    else if (a.epi == EPI_LINEAR)
+        hipLaunchKernelGGL((igemm_split_linw_kernel<4, EPI_LINEAR, true>), grid, dim3(256), 0, s, k);
+    else
+        hipLaunchKernelGGL((igemm_split_linw_kernel<4, EPI_TRCONV, true>), grid, dim3(256), 0, s, k);
     return 0;
 }
 
@@ -1191,8 +1203,8 @@ int launch_igemm_split(int cfg, const GemmArgs &a, hipStream_t s, bool dry, int 
 #define DMX_CASE(cfgid, WM_, WN_, MF, NF, PRO, EPI) \
     case (cfgid * 100 + PRO * 10 + EPI):           \
         return launch_split_one<WM_, WN_, MF, NF, PRO, EPI>(a, s, arith, dry);
-    if (cfg == 5 || cfg == 12) // 128x32 / 64x32
-        return launch_split_narrow(a, s, arith, dry);
+    if (cfg == 5 || cfg == 12 || cfg == 6 || cfg == 13) // 128x32 / 64x32, 128x64 / 64x64 (4 x 1 waves)
+        return launch_split_narrow(cfg, a, s, arith, dry);
     switch (cfg * 100 + a.pro * 10 + a.epi)
     {
         DMX_CASE(0, 2, 2, 4, 4, PRO_NONE, EPI_LINEAR)

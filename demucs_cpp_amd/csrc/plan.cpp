@@ -262,7 +262,12 @@ struct Builder
         // (igemm_split.hip, round 6): 0.900 -> 0.815 / 0.435 -> 0.386 ms at 42 segments against the fp32 direct kernel, which
         // sits on the fp32 matrix pipe's ridge; an fp32 context keeps the direct kernel (its tiled fp32 form is 20 % slower)
         const bool rewrite0Split = opts.gemm != GEMM_F32 && g.pro == PRO_NONE && g.epi == EPI_GLU && g.S1 == 1 && g.seg0 == 48 && g.N == 96;
-        if (resOk && !rewrite0Split && (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
+        // likewise the frequency branch's last transposed conv (48 -> 4 x Cout, K = 96): N = 64 (4 sources; igemm_split.hip
+        // launch_split_narrow: 0.947 -> 0.917 ms) and N = 96 (6 sources: 1.57 -> 1.22 ms). The time branch's (N = 32 / 48) stays on
+        // the direct kernel (N = 32 measured: 0.286 -> 0.293 ms)
+        const bool lastTrSplit = opts.gemm != GEMM_F32 && g.pro == PRO_NONE && g.epi == EPI_TRCONV && g.S1 == 1 && g.seg0 == 96 &&
+                                 (g.N == 64 || g.N == 96);
+        if (resOk && !rewrite0Split && !lastTrSplit && (direct_available(g.N, g.S1, g.seg0, g.pro, g.epi) ||
                       (g.epi == EPI_STATS_ONLY && direct_available(g.N, g.S1, g.seg0, g.pro, EPI_GN_GLU_SCALE_RES))))
             g.cfg = kDirectCfg;
         g.NB = (g.N + kTileCfgs[g.cfg].BN - 1) / kTileCfgs[g.cfg].BN;
