@@ -46,7 +46,8 @@ config also reports, as SCALAR keys, measured in this same run:
   track_strong_xRT / track_strong_wall_s   (every N, single-model workloads) ONE such track with its 42 segments dealt
                       over the N ranks (contiguous ranges), RCCL gather of the per-segment outputs to the root, root
                       overlap-add, D2H on the root: strong scaling of a single track (<= 87.5 % at N = 8: 42 = 6+6+5*6);
-  single_segment_latency_ms  BASELINE configs[1] read literally (one segment per call, device resident).
+  single_segment_latency_ms  BASELINE configs[1] read literally (one segment per call, device resident);
+  single_segment_launches    kernel launches of that call (one plan run at batch 1).
 
 Extra objects on the JSON line:
   roofline     : dominant kernel (by device time) measured live with HIP events on the stream
@@ -398,6 +399,7 @@ def main():
 
     # BASELINE.json configs[1] read literally: ONE segment per call (latency), device resident
     single_ms = None
+    single_launches = None
     if rank == 0 and world == 1 and not args.no_single:
         torch.cuda.synchronize()
         ctx.set_stream(None)  # the context's own stream: repeated identical calls replay a captured HIP graph
@@ -411,6 +413,8 @@ def main():
             ctx.synchronize()  # latency of ONE call: wait for every result before the next call
         single_ms = (time.perf_counter() - t1) / 10 * 1e3
         ctx.set_stream(stream.cuda_stream)
+        # kernel launches of one single-segment plan run (the ISTFT op runs inside the overlap-add kernel: no launch of its own)
+        single_launches = sum(1 for nm, *_ in ctx.profile(1, 1) if nm != "istft")
 
     # ---- the same 4-minute track end to end (host buffers in and out), and strong-scaled over the ranks
     # (segments dealt in contiguous ranges, RCCL gather, root overlap-add)
@@ -624,6 +628,7 @@ def main():
                        **{f"{other_keys[g]}_{k2}": (None if g not in other_runs else other_runs[g][k1])
                           for g in others for k1, k2 in (("xRT", "xRT"), ("ms_per_segment", "ms_per_segment"), ("finite", "outputs_finite"))},
                        "single_segment_latency_ms": None if single_ms is None else round(single_ms, 3),
+                       "single_segment_launches": single_launches,
                        "single_segment_xRT": None if single_ms is None else round(SEG_SECONDS / (single_ms * 1e-3), 1),
                        "parallelism": f"segment-sharded x{world}"},
         }
