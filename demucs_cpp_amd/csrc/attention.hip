@@ -271,8 +271,12 @@ __global__ __launch_bounds__(256, HS > 64 ? 1 : 2) void attention_kernel(const A
     __syncthreads();
     f32x4 sA[QF][4], sB[QF][4];
     scores_part(0, sA, 0, DF);
-    if constexpr (KDIRECT)
-        __syncthreads(); // step 0 requests K(2) straight into the buffer of K(0): every wave must have read K(0) first
+    // Step 0 puts K(2) into the buffer of K(0) - KDIRECT requests it at once, the register-staged form writes it at the END of the
+    // step: every wave must have read K(0) first. (Until round 6 only KDIRECT had this barrier: "a wave cannot fall a whole step
+    // behind" does not hold when eight contexts share the GPU - a late wave of a head-dim-48 launch then took part of K(2) for K(0)
+    // in its first tile: errors of 1e-6 .. 4e-5 in whole segments, caught by the eight-logical-device test of the 6-source model
+    // in fp32 mode, profiles/r06_experiments/attention48_prologue_race.txt.)
+    __syncthreads();
     // one pipelined step (PAR = t & 1, compile-time): softmax + PV of tile t from sCur, scores of tile t+1 into sNext
     auto step = [&](int t, auto parTag, f32x4 (*sCur)[4], f32x4 (*sNext)[4]) {
         constexpr int PAR = decltype(parTag)::value;
