@@ -18,6 +18,8 @@ def pytest_configure(config):
 #    (a v3 fp16x3 context builds the bf16x3 plan bit for bit: asserted once);
 #  * tests of host-side plumbing whose device work is mode-independent by construction (engine dealing / finish modes / RCCL
 #    transport, CLI sharding, the bag through the engine) run in the default arithmetic (bf16x3) only.
+#    Exception (round 6): the eight-logical-device run of the 6-source model also runs in f32 - eight contexts competing for one
+#    GPU is what exposed a barrier missing from the fp32 attention kernel's head-dim-48 form (attention.hip), which no quiet run shows.
 # DMX_TEST_ALL_MODES=1 runs everything in every mode (profiles/r05_gpu_tests.txt is such a run).
 FP16X3_KEEPS = ("test_reduced_segment_all_layers_vs_oracle_and_golden", "test_full_size_segment_vs_oracle", "test_batch_equals_singles_bitwise_and_layouts",
                 "test_bench_batch_and_awkward_lengths_equal_singles", "test_full_4min_track_end_to_end", "test_track_vs_oracle_reduced",
@@ -28,7 +30,7 @@ DEFAULT_MODE_ONLY = ("test_full_ft_bag_4min_track_over_one_and_eight_logical_dev
                      "test_cli_shards_over_dmx_devices_and_finish_modes", "test_engine_rccl_self_exchange_moves_the_slabs",
                      "test_engine_rccl_agrees_before_the_exchange", "test_engine_rccl_transport_binds_and_builds_a_communicator",
                      "test_engine_ft_bag_equals_four_sequential_runs_bitwise", "test_engine_owner_finish_mode_equals_root_gather_bitwise",
-                     "test_6s_4min_track_over_eight_logical_devices", "test_cli_mono_input_is_duplicated_to_stereo", "test_argument_errors",
+                     "test_cli_mono_input_is_duplicated_to_stereo", "test_argument_errors",
                      "test_shim_is_reentrant_and_eigen_overloads_match", "test_caller_stream_ordering_without_host_sync")
 
 
