@@ -1222,8 +1222,10 @@ def test_linear_layer_split_kernels_agree_bitwise(tmp_path):
     are the same bits, with one segment per call (small tiles, staged kernel either way) and with six. Round 6: the 128 x 256
     tile (igemm_split_linw_kernel: weight planes by LDS-DMA, 16 column fragments per wave) replaces the 128 x 128 one per
     LAUNCH where it pays - DMX_SPLIT_LIN=3 takes it wherever it exists (N % 256 == 0, no row statistics: linear1, q / k / qk /
-    v, out_proj, the 4s channel upsamplers), =2 never: the same bits again. The switch is read once per process: three child
-    processes (tools/gpu_lin_ab.py)."""
+    v, out_proj, the 4s channel upsamplers), =2 never: the same bits again. Later in round 6 the same kernel took conv addressing
+    (`GEN`) and the widths 192 / 96: with =3 every strided conv, 3x3 / k3 / 1x1 rewrite and transposed conv of the 128 x 128 /
+    128 x 96 tiles runs on it at every batch size, with =0 / =2 none does - still the same bits. The switch is read once per
+    process: three child processes (tools/gpu_lin_ab.py)."""
     import subprocess
     outs = []
     for mode in ("0", "2", "3"):
