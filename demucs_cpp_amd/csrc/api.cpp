@@ -916,10 +916,7 @@ static int launch_op(const dmx_ctx *c, const Op &op, hipStream_t s, i64 zeroOff)
     case OP_LAYERNORM:
     {
         const LayerNorm &l = op.ln;
-        LnArgs k{a(l.x), a(l.y), l.rows, l.D, l.rowsPerBatch, w(l.w_w), w(l.b_w), a(l.pe), l.eps};
-        if (l.gnStats >= 0)
-            k.gnStats = a(l.gnStats), k.gnW = w(l.gnW_w), k.gnB = w(l.gnB_w), k.xw = a(l.x);
-        launch_layernorm(k, s);
+        launch_layernorm(LnArgs{a(l.x), a(l.y), l.rows, l.D, l.rowsPerBatch, w(l.w_w), w(l.b_w), a(l.pe), l.eps}, s);
         break;
     }
     case OP_GN_APPLY:

@@ -136,10 +136,6 @@ struct LnArgs
     int rows, D, rowsPerBatch;
     const float *w, *b, *pe;
     float eps;
-    // plan.h LayerNorm::gnStats: per-sample {mean, rstd, ..} of the preceding GroupNorm(1, D), its affine, and x again as the
-    // write-back target; all null: plain LayerNorm
-    const float *gnStats = nullptr, *gnW = nullptr, *gnB = nullptr;
-    float *xw = nullptr;
 };
 void launch_layernorm(const LnArgs &a, hipStream_t s);
 

@@ -148,25 +148,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs p)
     const float *x = p.x + (i64)row * p.D;
     float v[8]; // D <= 512
     float s = 0.f;
-    // (round 6) the previous layer's norm_out on the way in: the sample's GroupNorm(1, D) applied with gn_apply_kernel's expression
-    // and written back to the residual stream
-    float gmean = 0.f, gsc = 1.f;
-    if (p.gnStats)
-    {
-        const int b = row / p.rowsPerBatch;
-        gmean = p.gnStats[b * 4];
-        gsc = p.gnStats[b * 4 + 1];
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
     {
         const int c = lane + i * 64;
         v[i] = c < p.D ? x[c] : 0.f;
-        if (p.gnStats && c < p.D)
-        {
-            v[i] = (v[i] - gmean) * gsc * p.gnW[c] + p.gnB[c];
-            p.xw[(i64)row * p.D + c] = v[i];
-        }
         s += v[i];
     }
 #pragma unroll

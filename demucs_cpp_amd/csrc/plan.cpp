@@ -661,13 +661,12 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
         b.push_gemm(name, stream, g);
     };
     auto layernorm = [&](const std::string &name, int stream, i64 x, i64 y, int rows, const std::string &w,
-                         const std::string &bs, i64 pe, i64 gnStats = -1, i64 gnW = -1, i64 gnB = -1) {
+                         const std::string &bs, i64 pe) {
         Op op;
         op.kind = OP_LAYERNORM;
         op.stream = stream;
         op.name = name;
         op.ln = LayerNorm{x, y, B * rows, D, rows, b.W(w), b.W(bs), pe, 1e-5f};
-        op.ln.gnStats = gnStats, op.ln.gnW_w = gnW, op.ln.gnB_w = gnB;
         pl.ops.push_back(op);
     };
     auto attention = [&](const std::string &name, int stream, i64 q, int ldq, i64 qB, i64 k, i64 v, int ldkv, i64 kvB,
@@ -726,13 +725,6 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
     b.push_tap("ct_in_x", aQf, {tokF, D}, (i64)tokF * D);
     b.push_tap("ct_in_xt", aQt, {tokT, D}, (i64)tokT * D);
 
-    // norm_out of layers 0 .. 3 (crosstransformer.cpp: the layer's last op, GroupNorm(1, D) of the branch's whole token block) is
-    // applied by the NEXT layer's norm1 on its way in (LayerNorm::gnStats: x rewritten, then normalised - one read of the residual
-    // stream instead of two); the last layer's stays an op of its own
-    struct PendingGn
-    {
-        i64 stats = -1, w = -1, bs = -1;
-    } pending[2];
     for (int layer = 0; layer < 5; ++layer)
     {
         const bool self = layer % 2 == 0;
@@ -750,16 +742,9 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
                     {ptn, 1, aQt, aNt, aN2t, aQKVt, aKVt, aAttT, aHidT, aStNt, aRsTt, tokT, tokF, aQf, aKplT, aVtT}};
         // phase 1: norms + projections (cross layers read the OTHER branch before it is
         // updated: "old_x" of crosstransformer.cpp:286-295)
-        // (both branches' norm1 first: it finishes the other branch's view of x, which the cross layers' norm2 reads)
-        for (int bi = 0; bi < 2; ++bi)
-        {
-            const Br &r = br[bi];
-            layernorm(r.p + ".norm1", r.stream, r.x, r.n, r.tok, r.p + ".norm1.w", r.p + ".norm1.b", -1, pending[bi].stats, pending[bi].w,
-                      pending[bi].bs);
-            pending[bi] = PendingGn{};
-        }
         for (auto &r : br)
         {
+            layernorm(r.p + ".norm1", r.stream, r.x, r.n, r.tok, r.p + ".norm1.w", r.p + ".norm1.b", -1);
             if (self && planes_ok(r.tok))
             {
                 // q (fp32, columns [0, D) of the [tok][3D] buffer) and the K planes in one launch, the V^T planes in a second
@@ -789,9 +774,8 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
             }
         }
         // phase 2: attention, out_proj, FFN, norm_out; layers.cpp:454-530
-        for (int bi = 0; bi < 2; ++bi)
+        for (auto &r : br)
         {
-            const Br &r = br[bi];
             if (self)
                 attention(r.p + ".attn", r.stream, r.qkv, 3 * D, (i64)r.tok * 3 * D, r.qkv + D, r.qkv + 2 * D, 3 * D,
                           (i64)r.tok * 3 * D, r.att, r.tok, r.tok, planes_ok(r.tok) ? r.kpl : -1, planes_ok(r.tok) ? r.vt : -1);
@@ -808,11 +792,6 @@ void build_plan(const PackedModel &pm, i64 seg, int B, Plan &pl, const PlanOpts 
                    EPI_SCALE_RES, 0, r.x, b.W(r.p + ".gamma_2"), r.rs);
             int NBl = pl.ops.back().g.NB;
             b.push_reduce(r.p + ".norm_out.stats", r.stream, r.rs, r.stn, B, r.tok, NBl, 1, (double)r.tok * D, MODE_RSTD);
-            if (layer < 4 && opts.fuseNormOut)
-            {
-                pending[bi].stats = r.stn, pending[bi].w = b.W(r.p + ".norm_out.w"), pending[bi].bs = b.W(r.p + ".norm_out.b");
-                continue;
-            }
             Op op;
             op.kind = OP_GN_APPLY;
             op.stream = r.stream;
@@ -1008,11 +987,6 @@ void op_access(const Op &op, std::vector<Range> &rd, std::vector<Range> &wr)
     case OP_LAYERNORM:
         R(op.ln.x, (i64)op.ln.rows * op.ln.D);
         Wr(op.ln.y, (i64)op.ln.rows * op.ln.D);
-        if (op.ln.gnStats >= 0)
-        {
-            R(op.ln.gnStats, (i64)(op.ln.rows / op.ln.rowsPerBatch) * 4);
-            Wr(op.ln.x, (i64)op.ln.rows * op.ln.D);
-        }
         break;
     case OP_GN_APPLY:
     {

@@ -159,10 +159,6 @@ struct LayerNorm
     i64 w_w, b_w; // W
     i64 pe;       // A constant [rowsPerBatch][D] added after the affine, or -1
     float eps;
-    // round 6: the previous transformer layer's norm_out (GroupNorm(1, D) over the sample's whole [rowsPerBatch][D] block, statistics
-    // {mean, rstd} of sample b at A[gnStats + 4 b]) applied on the way in - x = (x - mean) rstd gnW[c] + gnB[c] is WRITTEN BACK to x
-    // (the residual stream) and the LayerNorm is taken of it: one read of x instead of two (GnApply + LayerNorm). -1: none
-    i64 gnStats = -1, gnW_w = -1, gnB_w = -1;
 };
 
 struct GnApply
@@ -400,7 +396,6 @@ struct PlanOpts
 {
     int gemm = GEMM_F32;
     int kvPlanes = 0; // GEMM_BF16X3 only: K / V projections write the attention kernel's bf16 operand planes (EPI_KPL / EPI_VT)
-    int fuseNormOut = 1; // norm_out of transformer layers 0 .. 3 applied by the next layer's norm1 (LayerNorm::gnStats); 0: an op of its own
 };
 
 struct Plan

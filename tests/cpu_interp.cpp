@@ -260,13 +260,7 @@ struct Interp
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < l.rows; ++r)
         {
-            float *x = &A[(size_t)(l.x + (i64)r * l.D)];
-            if (l.gnStats >= 0) // the previous layer's norm_out on the way in, written back (plan.h LayerNorm::gnStats)
-            {
-                const float *st = &A[(size_t)(l.gnStats + 4 * (i64)(r / l.rowsPerBatch))];
-                for (int c = 0; c < l.D; ++c)
-                    x[c] = (x[c] - st[0]) * st[1] * W[l.gnW_w + c] + W[l.gnB_w + c];
-            }
+            const float *x = &A[(size_t)(l.x + (i64)r * l.D)];
             double s = 0;
             for (int c = 0; c < l.D; ++c)
                 s += x[c];
