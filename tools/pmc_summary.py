@@ -26,7 +26,7 @@ def kernel_class(name: str) -> str:
         return f"igemm_split_{4 * mf * 16}x{nf * 16}"
     m = re.search(r"igemm_split_linw_kernel<(\d+)", name)  # the wide tiles (128 x 256 / 192; 6 fragments: 128 x 96, direct fragments)
     if m:
-        return {16: "igemm_split_128x256", 12: "igemm_split_128x192"}.get(int(m.group(1)), "igemm_split_128x96d")
+        return {16: "igemm_split_128x256", 12: "igemm_split_128x192", 6: "igemm_split_128x96d", 4: "igemm_split_128x64d", 2: "igemm_split_128x32d"}[int(m.group(1))]
     if "dconv_row_kernel" in name:
         return "dconv_row"
     if "igemm_lin256_kernel" in name:
