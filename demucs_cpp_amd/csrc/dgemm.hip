@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const GemmArgs pa, const Fas
 // --------------------------------------------------------------------------- DConv K1: ONE read per input row
 // K1 = Conv1d(C -> C/8, k3, dilation d) along TIME. The three taps of an output row are the input rows at t-d, t, t+d,
 // so the generic kernel above fetches every input row three times through L1 / the texture addresser, which is what
-// bounds it (TA busy 76-84 %, 2.5-3.6 TB/s of algorithmic bytes). Here every LANE ROW of a wave
+// bounds it (profiles/DESIGN_history_r1-r4.md: TA busy 76-84 %, 2.5-3.6 TB/s of algorithmic bytes). Here every LANE ROW of a wave
 // walks the time axis and keeps the fragments of rows t-d .. t+d in a register ring (2d+2 slots: the window plus one
 // row in flight); each step loads only row t+d+1:
 //   frequency branch [B][T][F][C]: the 16 lane rows are 16 consecutive bins, all at the same t (a chunk of the walk
