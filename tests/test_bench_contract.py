@@ -138,6 +138,42 @@ def test_committed_round5_bench_lines():
     assert abs(h["value"] - three["config"]["fp16x3_xRT"]) / h["value"] < 0.02 and "bf16x3_xRT" not in h["config"]
 
 
+def test_committed_round6_bench_lines():
+    """Round 6: the dominant class is the 128 x 256 direct-fragment tile; the headline line was re-run at the head with the round's
+    counter files committed, so it quotes its own traffic and clock; `single_segment_launches` is on the line."""
+    rd = lambda n: json.loads(open(os.path.join(ROOT, "profiles", n)).read())
+    d = rd("r06_bench_4s_b42.json")
+    assert "htdemucs-4s" in d["metric"] and "configs[2]" in d["metric"]
+    _check_line(d, "r06_kernel_stats_b42_by_class.csv", rnd=6)
+    assert d["value"] >= 3000 and d["config"]["ms_per_segment"] <= 1.9
+    r = d["roofline"]
+    assert r["kernel"] == "igemm_split_128x256" and r["frac"] > 0.46 and r["traffic_source"] == "profiles/r06_traffic_bf16x3.json"
+    assert r["traffic"] is not None and r["traffic_ratio"] < 1.6 and r["effective_clock_source"] == "profiles/r06_effective_clock.csv"
+    assert 250 <= d["config"]["single_segment_launches"] <= 300 and d["config"]["single_segment_latency_ms"] < 4.5
+    coll = rd("r06_bench_4s_b42_collection.json")  # the line of the collection run itself (before its counter files existed)
+    assert abs(coll["value"] - d["value"]) / d["value"] < 0.03 and coll["roofline"]["kernel"] == r["kernel"]
+    for name, key in (("r06_bench_6s_b42.json", "configs[3]"), ("r06_bench_ft_b42.json", "configs[4]")):
+        x = rd(name)
+        assert key in x["metric"] and x["config"]["gemm_path"].startswith("bf16x3") and x["config"]["outputs_finite"] is True
+        assert 0.3 < x["roofline"]["whole_path_frac"] < 0.8
+    ft = rd("r06_bench_ft_b42.json")["config"]
+    assert ft["segments_per_gpu_per_step"] == 168 and ft["track_strong_items"] == 168 and ft["strong_ceiling"] == 1.0
+    assert rd("r06_bench_6s_b42.json")["config"]["strong_ceiling"] == 1.0  # (one rank: the ceiling of 42 items over 1)
+    assert "hdemucs_mmi" in rd("r06_bench_v3_b42.json")["metric"]
+    sweep = [json.loads(x) for x in open(os.path.join(ROOT, "profiles", "r06_bench_4s_b1_b4_b12_b24.jsonl")) if x.strip()]
+    ms = [x["config"]["ms_per_segment"] for x in sweep]
+    assert len(ms) == 4 and ms == sorted(ms, reverse=True) and ms[-1] > d["config"]["ms_per_segment"]
+    t = rd("r06_traffic_bf16x3.json")
+    assert t["batch"] == 42 and t["gemm"] == "bf16x3"
+    for cls in ("igemm_split_128x256", "igemm_split_128x192", "igemm_split_128x96d", "igemm_split_128x32d", "dconv_row", "attention_split"):
+        assert cls in t["classes"], cls
+    # the row-resident DConv moves its rows once: counter bytes within 10 % of read + write of x
+    dr = t["classes"]["dconv_row"]
+    assert dr["launches"] % 4 == 0 and 0.95 < dr["read_bytes_per_launch"] / dr["write_bytes_per_launch"] < 1.15
+    h = rd("r06_bench_4s_b42_fp16x3.json")
+    assert h["config"]["gemm_path"].startswith("fp16x3") and "fp16x3" in h["dtype"] and h["roofline"]["kernel"] == "igemm_splith_128x128"
+
+
 def test_round2_bench_line_still_parses():
     d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_b24.json")).read())
     assert d["config"]["track_4min_xRT"]["segments"] == 42 and d["roofline"]["kernel"] == "igemm_128x128"
