@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""ROOT and OWNER finish of an 8-logical-device engine on one GPU against one context's track result, three rounds; prints where
+(stems, sample range, segments) and by how much a mismatching run differs. MODE=f32|bf16x3, NS=4|6. (Round 6: the first reproducer
+of the attention.hip head-dim-48 race; tools/concurrency_diag.py localises by layer taps.)"""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 from demucs_cpp_amd import binding as dmx
