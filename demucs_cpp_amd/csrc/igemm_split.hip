@@ -544,6 +544,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_lin_kernel(const GemmArgs 
 // 384 levels were two (N = 192) to six (N = 768) 96- or 128-wide tiles that each fetched AND split the same activation rows;
 // here a row is fetched and split once per 192 / 256 columns and never passes through LDS. K-tile order, chunk -> (run, tap)
 // walk and term order are those of igemm_split_kernel: the same bits (per-launch choice, tools/gpu_lin_ab.py).
+// The narrow forms (WNF = 6 / 4 / 2: 96 / 64 / 32 columns) have the staged tiles' workgroup count; what they drop is the LDS round
+// trip of the activations, and their small register files fit three to four workgroups per CU (launch_wide_conv /
+// launch_split_narrow; measured per form: profiles/r06_experiments/).
 template <int WNF, int EPI, bool GEN>
 __global__ __launch_bounds__(256, WNF == 2 ? 4 : WNF <= 6 ? 3 : 2) void igemm_split_linw_kernel(const GemmArgs p)
 {
